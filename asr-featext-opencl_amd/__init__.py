@@ -1,0 +1,26 @@
+"""asr-featext-opencl_amd -- MI355X (gfx950) MFCC front end.
+
+Python side of the drop-in boundary: thin ctypes bindings over ``libmfcchip.so`` (the C ABI of
+``include/mfx.h``).  The compiled host mirror of the reference's ``ParamBase``/``MfccBase`` classes
+lives in ``host/`` (C++); this module offers the same interface to Python callers and tests.
+
+There is no CPU fallback here: if the shared library is missing or no HIP device is present the
+constructors raise.  (The directory name is not an importable identifier; load it with
+``importlib`` as ``__graft_entry__.load_package()`` does, or put the parent directory on
+``sys.path`` and use ``importlib.import_module("asr-featext-opencl_amd")``.)
+"""
+from .mfcc import (  # noqa: F401
+    DYN_ACC,
+    DYN_DELTA,
+    DYN_NONE,
+    NORM_CMN,
+    NORM_CVN,
+    NORM_MINMAX,
+    NORM_NONE,
+    MfccHip,
+    MfxConfig,
+    MfxError,
+    library_path,
+    load_library,
+    reference_window,
+)

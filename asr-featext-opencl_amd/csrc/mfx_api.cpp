@@ -1,0 +1,986 @@
+// mfx_api.cpp -- the C ABI of include/mfx.h: handle, streaming state machine, batch planner.
+//
+// The streaming bookkeeping restates the reference's segmenter and apply() state machines
+// (segmentercpu.cpp:56-106 / segmenteropencl.cpp:120-175, mfcccpu.cpp:371-425 /
+// mfccopencl.cpp:495-549) on top of device buffers; all arithmetic on samples and features happens
+// in the HIP kernels of mfx_kernels.hip.  There is deliberately no CPU compute path in this file.
+#include "../../include/mfx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mfx_kernels.h"
+#include "mfx_tables.h"
+
+using namespace mfx;
+
+namespace {
+
+const char *kMsgBuffer = "Can't process data, buffer is too small";
+const char *kMsgWindow = "Can't process data, window count is too small";
+const char *kMsgProcessed = "Processed samples <= 0, this should never happen";
+const char *kMsgHigh = "Window count too high";
+
+constexpr int kChunkFrames = 64; // frames per work item of the front-end kernels
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc((void **)&p, count * sizeof(T));
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+} // namespace
+
+struct mfx_handle {
+    mfx_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // derived (mfccbase.cpp:18-30, mfcccpu.cpp:94-105)
+    int W = 0, S = 0, W2 = 0, nb = 0, ceps = 0, dl = 0, cols = 0, width = 0;
+    int l1 = 0, l2 = 0, D = 0;
+    int input_window_limit = 0, input_buffer_size = 0, window_limit = 0;
+    int spec_pitch = 0;
+    int channels = 1;
+    bool fast512 = false;
+    int nm16 = 16;
+    float alpha = 1.f, table_alpha = -1.f;
+    bool have_window = false;
+
+    // tables in HBM
+    DevBuf<float> d_window, d_winpair, d_twid_pass, d_twid_half, d_twid_split, d_mel_w, d_dct;
+    DevBuf<int32_t> d_mel_beg;
+
+    // streaming state (segmentercpu.h:7-17, parambase.h:18)
+    DevBuf<int16_t> d_carry[2];
+    int cur = 0;
+    size_t carry_capacity = 0;
+    int remaining = 0, samples = 0;
+    bool flushed = true, last_calc_flushed = false, last_block = false;
+    int block_wcnd = 0;      // frames (with context) the last FFT covered
+    int block_frames = 0;    // frames apply() delivers
+    bool block_applied = false;
+    DevBuf<float> d_spec, d_src, d_blk, d_stats_stream;
+    DevBuf<Chunk> d_chunks_stream;
+    int n_chunks_stream_max = 0;
+    int16_t *h_stage = nullptr; // pinned
+    size_t h_stage_n = 0;
+
+    // batch plan
+    int32_t n_utt = 0;
+    int64_t total_rows = 0;
+    std::vector<int64_t> utt_off, utt_len, utt_row;
+    std::vector<Chunk> h_chunks;
+    DevBuf<Chunk> d_chunks;
+    DevBuf<Segment> d_segs;
+    DevBuf<float> d_stats_batch, d_spec_slab;
+    int tiles_max = 0;
+    bool batch_aligned = true;
+
+    // profiling of the dominant kernel
+    bool prof_on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t prof_used = 0;
+    int prof_launches = 0;
+    double prof_ms = 0;
+};
+
+namespace {
+
+int fail(mfx_handle *h, int code, const std::string &msg)
+{
+    if (h) h->err = msg;
+    return code;
+}
+
+int fail_hip(mfx_handle *h, hipError_t e, const char *what)
+{
+    std::string m = std::string(what) + ": " + hipGetErrorString(e);
+    return fail(h, MFX_ERR_DEVICE, m);
+}
+
+#define HIP_TRY(h, expr)                                         \
+    do {                                                         \
+        hipError_t _e = (expr);                                  \
+        if (_e != hipSuccess) return fail_hip((h), _e, #expr);   \
+    } while (0)
+
+template <class T>
+hipError_t upload(DevBuf<T> &b, const std::vector<T> &v)
+{
+    hipError_t e = b.alloc(v.size());
+    if (e != hipSuccess || v.empty()) return e;
+    return hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+// rebuild the alpha-dependent mel table if needed (the reference re-derives it on every apply(),
+// mfcccpu.cpp:194; here only when alpha actually changed)
+int refresh_mel(mfx_handle *h)
+{
+    if (h->table_alpha == h->alpha && h->d_mel_w.p) return MFX_OK;
+    MelTable t;
+    build_mel_table(h->nb, h->W2, h->cfg.sample_rate, h->cfg.low_freq, h->cfg.high_freq, h->alpha, t);
+    // every filter edge must address a computed bin
+    for (int v : t.beg)
+        if (v < 0 || v > h->W2 / 2) return fail(h, MFX_ERR_CONFIG, "mel filter edge outside [0, fft_size/2]");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, upload(h->d_mel_w, t.weights));
+    HIP_TRY(h, upload(h->d_mel_beg, t.beg));
+    h->table_alpha = h->alpha;
+    return MFX_OK;
+}
+
+void fill_front(const mfx_handle *h, FrontParams &p)
+{
+    std::memset(&p, 0, sizeof(p));
+    p.channels = h->channels;
+    p.window_size = h->W;
+    p.shift = h->S;
+    p.fft_size = h->W2;
+    p.window = h->d_window.p;
+    p.winpair = h->d_winpair.p;
+    p.twid_pass = h->d_twid_pass.p;
+    p.twid_half = h->d_twid_half.p;
+    p.twid_split = h->d_twid_split.p;
+    p.mel_w = h->d_mel_w.p;
+    p.mel_beg = h->d_mel_beg.p;
+    p.dct = h->ceps > 0 ? h->d_dct.p : nullptr;
+    p.num_banks = h->nb;
+    p.dct_len = h->dl;
+    p.cols = h->cols;
+    p.scale = 0.5f / (float)h->W2;
+}
+
+struct ProfScope {
+    mfx_handle *h;
+    hipEvent_t a = nullptr, b = nullptr;
+    explicit ProfScope(mfx_handle *hh) : h(hh)
+    {
+        if (!h->prof_on) return;
+        if (h->prof_used == h->prof_events.size()) {
+            hipEvent_t x, y;
+            if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) return;
+            h->prof_events.emplace_back(x, y);
+        }
+        a = h->prof_events[h->prof_used].first;
+        b = h->prof_events[h->prof_used].second;
+        ++h->prof_used;
+        (void)hipEventRecord(a, h->stream);
+    }
+    ~ProfScope()
+    {
+        if (b) (void)hipEventRecord(b, h->stream);
+    }
+};
+
+int prof_collect(mfx_handle *h)
+{
+    if (h->prof_used == 0) return MFX_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < h->prof_used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->prof_events[i].first, h->prof_events[i].second) == hipSuccess) {
+            h->prof_ms += ms;
+            ++h->prof_launches;
+        }
+    }
+    h->prof_used = 0;
+    return MFX_OK;
+}
+
+// ---- normalisation helper: stats (unless reused) + apply over one column group
+int run_norm(mfx_handle *h, float *data, int pitch, int col0, const Segment *segs, int n_segs, const Segment *seg0,
+             int row_off, float *stats, bool use_last)
+{
+    NormParams np;
+    std::memset(&np, 0, sizeof(np));
+    np.data = data;
+    np.pitch = pitch;
+    np.col0 = col0;
+    np.cols = h->cols;
+    np.segs = segs;
+    np.n_segs = n_segs;
+    np.row_off = row_off;
+    np.norm_type = h->cfg.norm;
+    np.stats = stats;
+    if (seg0) {
+        np.inline_seg = 1;
+        np.seg0 = *seg0;
+        np.n_segs = 1;
+    }
+    if (!use_last) HIP_TRY(h, launch_norm_stats(np, h->stream));
+    HIP_TRY(h, launch_norm_apply(np, h->stream));
+    return MFX_OK;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// lifetime
+// ------------------------------------------------------------------------------------------------
+
+extern "C" int mfx_abi_version(void) { return MFX_ABI_VERSION; }
+
+extern "C" const char *mfx_status_string(int status)
+{
+    switch (status) {
+    case MFX_OK: return "ok";
+    case MFX_ERR_BUFFER_TOO_SMALL: return kMsgBuffer;
+    case MFX_ERR_WINDOW_COUNT: return kMsgWindow;
+    case MFX_ERR_PROCESSED: return kMsgProcessed;
+    case MFX_ERR_WINDOW_HIGH: return kMsgHigh;
+    case MFX_ERR_CONFIG: return "invalid configuration";
+    case MFX_ERR_DEVICE: return "HIP device error";
+    case MFX_ERR_ARG: return "invalid argument";
+    case MFX_ERR_STATE: return "call out of sequence";
+    default: return "unknown status";
+    }
+}
+
+extern "C" const char *mfx_last_error(const mfx_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" void mfx_destroy(mfx_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto &ev : h->prof_events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    h->d_window.release();
+    h->d_winpair.release();
+    h->d_twid_pass.release();
+    h->d_twid_half.release();
+    h->d_twid_split.release();
+    h->d_mel_w.release();
+    h->d_dct.release();
+    h->d_mel_beg.release();
+    h->d_carry[0].release();
+    h->d_carry[1].release();
+    h->d_spec.release();
+    h->d_src.release();
+    h->d_blk.release();
+    h->d_stats_stream.release();
+    h->d_chunks_stream.release();
+    h->d_chunks.release();
+    h->d_segs.release();
+    h->d_stats_batch.release();
+    h->d_spec_slab.release();
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **out)
+{
+    if (!cfg || !out) return MFX_ERR_ARG;
+    *out = nullptr;
+    if (cfg->window_size <= 0 || cfg->shift <= 0 || cfg->num_banks <= 0 || cfg->ceps_len < 0 ||
+        cfg->sample_rate <= 0 || cfg->norm < 0 || cfg->norm > 3 || cfg->dyn < 0 || cfg->dyn > 2 ||
+        cfg->channels < 0 || cfg->channels > 2)
+        return MFX_ERR_CONFIG;
+    if (cfg->ceps_len > 0 && cfg->lift_coef == 0.f) return MFX_ERR_CONFIG; // reference divides by lift_coef
+    if (cfg->dyn != MFX_DYN_NONE && cfg->delta_l1 <= 0) return MFX_ERR_CONFIG;
+    if (cfg->dyn == MFX_DYN_ACC && cfg->delta_l2 <= 0) return MFX_ERR_CONFIG;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hip_device < 0 || hip_device >= ndev)
+        return MFX_ERR_DEVICE; // no CPU fallback by design
+    if (hipSetDevice(hip_device) != hipSuccess) return MFX_ERR_DEVICE;
+
+    mfx_handle *h = new mfx_handle();
+    h->cfg = *cfg;
+    h->device = hip_device;
+    h->W = cfg->window_size;
+    h->S = cfg->shift;
+    h->nb = cfg->num_banks;
+    h->ceps = cfg->ceps_len;
+    h->l1 = cfg->dyn != MFX_DYN_NONE ? cfg->delta_l1 : 0;
+    h->l2 = cfg->dyn == MFX_DYN_ACC ? cfg->delta_l2 : 0;
+    h->D = h->l1 + h->l2;
+    h->dl = cfg->want_c0 ? cfg->ceps_len + 1 : cfg->ceps_len;
+    h->cols = h->ceps > 0 ? h->dl : h->nb;
+    h->width = h->cols * (cfg->dyn == MFX_DYN_ACC ? 3 : cfg->dyn == MFX_DYN_DELTA ? 2 : 1);
+    h->channels = cfg->channels == 2 ? 2 : 1;
+    h->W2 = (int)ceil_pow2((uint32_t)h->W);
+    if (cfg->fft_size != 0) {
+        if (cfg->fft_size < h->W || (cfg->fft_size & (cfg->fft_size - 1)) != 0) {
+            delete h;
+            return MFX_ERR_CONFIG;
+        }
+        h->W2 = cfg->fft_size;
+    }
+    if (h->W2 < 64 || h->W2 > 4096) {
+        delete h;
+        return MFX_ERR_CONFIG;
+    }
+    // ParamBase ctor (parambase.cpp:4-14)
+    h->input_window_limit = estimated_window_count_f32(cfg->input_buffer_size, h->W, h->S);
+    h->input_buffer_size = h->input_window_limit * h->S + h->W - h->S;
+    // MfccCpu ctor (mfcccpu.cpp:95-103)
+    h->window_limit = h->input_window_limit + 2 + (cfg->dyn != MFX_DYN_NONE ? 3 * h->D : 0);
+    if (h->input_window_limit <= 0 || h->window_limit <= 0) {
+        delete h;
+        return MFX_ERR_CONFIG;
+    }
+    h->spec_pitch = ((h->W2 / 2 + 1) + 3) & ~3;
+    h->fast512 = front512_supported(h->W2, h->W, h->nb, h->cols, h->channels);
+    h->nm16 = (h->W + 31) / 32;
+
+    int rc = MFX_OK;
+    auto bail = [&](int code) {
+        std::string msg = h->err;
+        mfx_destroy(h);
+        (void)msg;
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(MFX_ERR_DEVICE);
+    h->own_stream = true;
+
+    // ---- constant tables
+    {
+        std::vector<float> tw;
+        build_twiddles(h->W2 / 2, std::max(1, h->W2 / 4), tw); // W_M^k, k < M/2
+        if (upload(h->d_twid_half, tw) != hipSuccess) return bail(MFX_ERR_DEVICE);
+        std::vector<float> ws;
+        build_twiddles(h->W2, h->W2 / 2 + 1, ws); // W_{W2}^k
+        std::vector<float> split(ws.size());
+        for (int k = 0; k <= h->W2 / 2; ++k) { // -i * W = (wi, -wr)
+            split[2 * k] = ws[2 * k + 1];
+            split[2 * k + 1] = -ws[2 * k];
+        }
+        if (upload(h->d_twid_split, split) != hipSuccess) return bail(MFX_ERR_DEVICE);
+        if (h->fast512) {
+            std::vector<float> full;
+            build_twiddles(256, 256, full); // W_256^e
+            std::vector<float> pass(16 * 16 * 2);
+            for (int l = 0; l < 16; ++l)
+                for (int k = 0; k < 16; ++k) {
+                    int e = (l * k) & 255;
+                    pass[2 * (l * 16 + k)] = full[2 * e];
+                    pass[2 * (l * 16 + k) + 1] = full[2 * e + 1];
+                }
+            if (upload(h->d_twid_pass, pass) != hipSuccess) return bail(MFX_ERR_DEVICE);
+        }
+        if (h->ceps > 0) {
+            std::vector<float> m;
+            build_dct_matrix(h->nb, h->ceps, cfg->want_c0 != 0, cfg->lift_coef, m);
+            if (upload(h->d_dct, m) != hipSuccess) return bail(MFX_ERR_DEVICE);
+        }
+    }
+    rc = refresh_mel(h);
+    if (rc != MFX_OK) return bail(rc);
+
+    // ---- streaming buffers (capacity as the reference: segmentercpu.cpp:40-41, mfcccpu.cpp:104-112)
+    h->carry_capacity = (size_t)h->window_limit * h->S + h->W - h->S;
+    const size_t carry_alloc = (h->carry_capacity + h->W2 + 8) & ~(size_t)1;
+    for (int i = 0; i < 2; ++i) {
+        if (h->d_carry[i].alloc(carry_alloc) != hipSuccess) return bail(MFX_ERR_DEVICE);
+        if (hipMemset(h->d_carry[i].p, 0, carry_alloc * sizeof(int16_t)) != hipSuccess) return bail(MFX_ERR_DEVICE);
+    }
+    if (h->d_spec.alloc((size_t)h->window_limit * h->spec_pitch) != hipSuccess) return bail(MFX_ERR_DEVICE);
+    if (h->d_src.alloc((size_t)h->window_limit * h->cols) != hipSuccess) return bail(MFX_ERR_DEVICE);
+    if (h->d_blk.alloc((size_t)h->window_limit * h->width) != hipSuccess) return bail(MFX_ERR_DEVICE);
+    if (h->d_stats_stream.alloc((size_t)3 * 2 * h->cols) != hipSuccess) return bail(MFX_ERR_DEVICE);
+    if (hipMemset(h->d_stats_stream.p, 0, (size_t)3 * 2 * h->cols * sizeof(float)) != hipSuccess)
+        return bail(MFX_ERR_DEVICE);
+    {
+        h->n_chunks_stream_max = (h->window_limit + kChunkFrames - 1) / kChunkFrames;
+        std::vector<Chunk> ch(h->n_chunks_stream_max);
+        for (int i = 0; i < h->n_chunks_stream_max; ++i) {
+            ch[i].pcm_off = (int64_t)i * kChunkFrames * h->S;
+            ch[i].out_row = (int64_t)i * kChunkFrames;
+            ch[i].n_frames = kChunkFrames;
+            ch[i].pad = 0;
+        }
+        if (upload(h->d_chunks_stream, ch) != hipSuccess) return bail(MFX_ERR_DEVICE);
+    }
+    h->h_stage_n = (size_t)h->input_buffer_size;
+    if (hipHostMalloc((void **)&h->h_stage, h->h_stage_n * sizeof(int16_t), hipHostMallocDefault) != hipSuccess)
+        return bail(MFX_ERR_DEVICE);
+
+    *out = h;
+    return MFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// simple accessors
+// ------------------------------------------------------------------------------------------------
+
+extern "C" int mfx_get_output_data_width(const mfx_handle *h) { return h ? h->width : MFX_ERR_ARG; }
+extern "C" int mfx_get_input_buffer_size(const mfx_handle *h) { return h ? h->input_buffer_size : MFX_ERR_ARG; }
+extern "C" int mfx_estimated_window_count(const mfx_handle *h, int32_t samples)
+{
+    return h ? estimated_window_count_f32(samples, h->W, h->S) : MFX_ERR_ARG;
+}
+extern "C" int mfx_max_frames_out(const mfx_handle *h) { return h ? h->input_window_limit + 2 : MFX_ERR_ARG; }
+extern "C" int mfx_fft_size(const mfx_handle *h) { return h ? h->W2 : MFX_ERR_ARG; }
+
+extern "C" int mfx_set_alpha(mfx_handle *h, float alpha)
+{
+    if (!h) return MFX_ERR_ARG;
+    h->alpha = alpha;
+    return MFX_OK;
+}
+
+extern "C" int mfx_set_stream(mfx_handle *h, void *hip_stream)
+{
+    if (!h) return MFX_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->stream) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    return MFX_OK;
+}
+
+extern "C" int mfx_synchronize(mfx_handle *h)
+{
+    if (!h) return MFX_ERR_ARG;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MFX_OK;
+}
+
+extern "C" int mfx_profile_enable(mfx_handle *h, int enable)
+{
+    if (!h) return MFX_ERR_ARG;
+    int rc = prof_collect(h);
+    h->prof_on = enable != 0;
+    return rc;
+}
+
+extern "C" int mfx_profile_read(mfx_handle *h, int32_t *launches, double *kernel_ms, int reset)
+{
+    if (!h) return MFX_ERR_ARG;
+    int rc = prof_collect(h);
+    if (rc != MFX_OK) return rc;
+    if (launches) *launches = h->prof_launches;
+    if (kernel_ms) *kernel_ms = h->prof_ms;
+    if (reset) {
+        h->prof_launches = 0;
+        h->prof_ms = 0;
+    }
+    return MFX_OK;
+}
+
+extern "C" const char *mfx_dominant_kernel_name(const mfx_handle *h)
+{
+    if (!h) return "";
+    return h->fast512 ? "k_front512" : "k_front_generic";
+}
+
+// ------------------------------------------------------------------------------------------------
+// streaming interface
+// ------------------------------------------------------------------------------------------------
+
+extern "C" int mfx_set_window(mfx_handle *h, const float *window)
+{
+    if (!h || !window) return MFX_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<float> padded((size_t)h->W2, 0.f);
+    std::memcpy(padded.data(), window, sizeof(float) * h->W);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, upload(h->d_window, padded));
+    if (h->fast512) {
+        std::vector<float> wp(16 * 16 * 2, 0.f);
+        for (int l = 0; l < 16; ++l)
+            for (int m = 0; m < 16; ++m) {
+                int n = l + 16 * m;
+                wp[2 * (l * 16 + m)] = padded[2 * n];
+                wp[2 * (l * 16 + m) + 1] = padded[2 * n + 1];
+            }
+        HIP_TRY(h, upload(h->d_winpair, wp));
+    }
+    h->have_window = true;
+    return MFX_OK;
+}
+
+namespace {
+
+// frame + window + FFT + magnitude over the first `wcnd` frames of the carry buffer
+int stream_front(mfx_handle *h, int wcnd)
+{
+    FrontParams p;
+    fill_front(h, p);
+    p.pcm = h->d_carry[h->cur].p;
+    p.pcm_total = (int64_t)h->d_carry[h->cur].n;
+    p.chunks = h->d_chunks_stream.p;
+    p.n_chunks = (wcnd + kChunkFrames - 1) / kChunkFrames;
+    p.row_limit = wcnd;
+    p.channels = 1;
+    p.spec = h->d_spec.p;
+    p.spec_pitch = h->spec_pitch;
+    if (h->fast512)
+        HIP_TRY(h, launch_front512(p, /*to_spectrum=*/true, /*aligned=*/(h->S % 2) == 0, h->nm16, h->stream));
+    else
+        HIP_TRY(h, launch_front_generic(p, h->stream));
+    h->block_wcnd = wcnd;
+    return MFX_OK;
+}
+
+// move the unconsumed tail to the front of the other carry buffer (the reference copies inside
+// one buffer with overlapping ranges: segmentercpu.cpp:73,92 / segmenteropencl.cpp:139,160)
+int carry_tail(mfx_handle *h, int total_samples)
+{
+    const int other = h->cur ^ 1;
+    if (h->remaining > 0)
+        HIP_TRY(h, hipMemcpyAsync(h->d_carry[other].p, h->d_carry[h->cur].p + (total_samples - h->remaining),
+                                  sizeof(int16_t) * (size_t)h->remaining, hipMemcpyDeviceToDevice, h->stream));
+    h->cur = other;
+    return MFX_OK;
+}
+
+} // namespace
+
+extern "C" int mfx_set_input(mfx_handle *h, const int16_t *pcm, int32_t samples, int32_t *frames_out)
+{
+    if (!h || !pcm || !frames_out || samples < 0) return MFX_ERR_ARG;
+    *frames_out = 0;
+    if (!h->have_window) return fail(h, MFX_ERR_STATE, "set_window has not been called");
+    if (samples > h->input_buffer_size) return fail(h, MFX_ERR_BUFFER_TOO_SMALL, kMsgBuffer);
+    HIP_TRY(h, hipSetDevice(h->device));
+    h->last_block = false; // a new stream may follow a flush (reference never resets this: DESIGN.md B7)
+    h->block_applied = false;
+    h->block_frames = 0;
+
+    const int D = h->D, W = h->W, S = h->S;
+    // the caller may overwrite `pcm` as soon as we return: stage through pinned memory
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::memcpy(h->h_stage, pcm, sizeof(int16_t) * (size_t)samples);
+
+    h->last_calc_flushed = h->flushed;
+    int window_count = 0, wcnd = 0;
+    if (h->last_calc_flushed) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_carry[h->cur].p, h->h_stage, sizeof(int16_t) * (size_t)samples,
+                                  hipMemcpyHostToDevice, h->stream));
+        wcnd = estimated_window_count_f32(samples, W, S);
+        window_count = wcnd - D;
+        if (window_count <= 0) return fail(h, MFX_ERR_WINDOW_COUNT, kMsgWindow);
+        const int processed = (window_count - D) * S + W - S;
+        if (processed <= 0) return fail(h, MFX_ERR_PROCESSED, kMsgProcessed);
+        int rc = stream_front(h, wcnd);
+        if (rc != MFX_OK) return rc;
+        h->remaining = samples - processed + W - S;
+        rc = carry_tail(h, samples);
+        if (rc != MFX_OK) return rc;
+        h->flushed = false;
+        h->samples = samples;
+    } else {
+        if ((size_t)samples + (size_t)h->remaining > h->carry_capacity) return fail(h, MFX_ERR_BUFFER_TOO_SMALL, kMsgBuffer);
+        HIP_TRY(h, hipMemcpyAsync(h->d_carry[h->cur].p + h->remaining, h->h_stage, sizeof(int16_t) * (size_t)samples,
+                                  hipMemcpyHostToDevice, h->stream));
+        const int total = samples + h->remaining;
+        wcnd = estimated_window_count_f32(total, W, S);
+        window_count = wcnd - 2 * D;
+        if (window_count > 0) {
+            int rc = stream_front(h, wcnd);
+            if (rc != MFX_OK) return rc;
+        } else
+            window_count = 0;
+        const int processed = window_count * S + W - S;
+        h->remaining = total - processed + W - S;
+        int rc = carry_tail(h, total);
+        if (rc != MFX_OK) return rc;
+        h->samples = total;
+    }
+    h->block_frames = window_count;
+    *frames_out = window_count;
+    return MFX_OK;
+}
+
+extern "C" int mfx_flush(mfx_handle *h, int32_t *frames_out)
+{
+    if (!h || !frames_out) return MFX_ERR_ARG;
+    *frames_out = 0;
+    if (h->last_block) return MFX_OK; // nothing to flush (mfcccpu.cpp:350-351)
+    HIP_TRY(h, hipSetDevice(h->device));
+    h->last_block = true;
+    h->flushed = true;
+    h->block_applied = false;
+    h->block_frames = 0;
+    const int wcnd = estimated_window_count_f32(h->remaining, h->W, h->S);
+    const int window_count = wcnd - h->D;
+    if (window_count <= 0) return MFX_OK;
+    int rc = stream_front(h, wcnd);
+    if (rc != MFX_OK) return rc;
+    h->block_frames = window_count;
+    *frames_out = window_count;
+    return MFX_OK;
+}
+
+extern "C" int mfx_apply(mfx_handle *h)
+{
+    if (!h) return MFX_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int D = h->D;
+    int wcnd, wc;
+    bool first = false, last = false, use_last = false;
+    // the three cases of mfcccpu.cpp:371-425
+    if (h->last_block) {
+        wcnd = estimated_window_count_f32(h->remaining, h->W, h->S);
+        wc = wcnd - D;
+        last = true;
+        use_last = true;
+        if (wc <= 0) return MFX_OK;
+    } else if (h->last_calc_flushed) {
+        wcnd = estimated_window_count_f32(h->samples, h->W, h->S);
+        wc = wcnd - D;
+        first = true;
+        if (wc <= 0) return fail(h, MFX_ERR_WINDOW_COUNT, kMsgWindow);
+    } else {
+        wcnd = estimated_window_count_f32(h->samples, h->W, h->S);
+        wc = wcnd - 2 * D;
+        if (wc <= 0) return MFX_OK;
+    }
+    if (wcnd > h->window_limit) return fail(h, MFX_ERR_WINDOW_HIGH, kMsgHigh);
+
+    int rc = refresh_mel(h);
+    if (rc != MFX_OK) return rc;
+
+    // filterbank + log + DCT over all frames with context
+    MelcepParams mp;
+    std::memset(&mp, 0, sizeof(mp));
+    mp.spec = h->d_spec.p;
+    mp.spec_pitch = h->spec_pitch;
+    mp.n_rows = wcnd;
+    mp.feat = h->d_src.p;
+    mp.feat_pitch = h->cols;
+    mp.fft_size = h->W2;
+    mp.mel_w = h->d_mel_w.p;
+    mp.mel_beg = h->d_mel_beg.p;
+    mp.dct = h->ceps > 0 ? h->d_dct.p : nullptr;
+    mp.num_banks = h->nb;
+    mp.dct_len = h->dl;
+    mp.cols = h->cols;
+    HIP_TRY(h, launch_melcep(mp, h->stream));
+
+    const bool norm = h->cfg.norm != MFX_NORM_NONE;
+    Segment sg;
+    std::memset(&sg, 0, sizeof(sg));
+    if (norm && !h->cfg.norm_after_dyn) { // normalise statics (with context) before the deltas
+        sg.out_row0 = 0;
+        sg.n_out = wcnd;
+        rc = run_norm(h, h->d_src.p, h->cols, 0, nullptr, 1, &sg, 0, h->d_stats_stream.p, use_last);
+        if (rc != MFX_OK) return rc;
+    }
+
+    // static row offset as the reference reads it (mfcccpu.cpp:274,439): was_flushed() ? 0 : D.
+    // With bug_compat off a flush block always reads at D (fixes B1).
+    bool at_zero = h->last_calc_flushed;
+    if (!h->cfg.bug_compat && h->last_block) at_zero = false;
+    const int static_off = at_zero ? 0 : D;
+
+    DeltaParams dp;
+    std::memset(&dp, 0, sizeof(dp));
+    dp.src = h->d_src.p;
+    dp.src_pitch = h->cols;
+    dp.out = h->d_blk.p;
+    dp.out_pitch = h->width;
+    dp.n_segs = 1;
+    dp.cols = h->cols;
+    dp.l1 = h->l1;
+    dp.l2 = h->l2;
+    dp.tiles_per_seg_max = (wc + 63) / 64;
+    dp.inline_seg = 1;
+    sg.src_row0 = 0;
+    sg.out_row0 = 0;
+    sg.n_out = wc;
+    sg.static_off = static_off;
+    if (first) { // D replicated rows in front (mfcccpu.cpp:243-248)
+        sg.shift = -D;
+        sg.lo = 0;
+        sg.hi = wcnd - 1;
+    } else if (last) { // D replicated rows behind (mfcccpu.cpp:249-254)
+        sg.shift = 0;
+        sg.lo = 0;
+        sg.hi = wc + D - 1;
+    } else {
+        sg.shift = 0;
+        sg.lo = 0;
+        sg.hi = wcnd - 1;
+    }
+    dp.seg0 = sg;
+    HIP_TRY(h, launch_delta(dp, h->stream));
+
+    if (norm && h->cfg.norm_after_dyn) {
+        Segment so;
+        std::memset(&so, 0, sizeof(so));
+        so.out_row0 = 0;
+        so.n_out = wc;
+        const int groups = h->width / h->cols;
+        for (int g = 0; g < groups; ++g) {
+            rc = run_norm(h, h->d_blk.p, h->width, g * h->cols, nullptr, 1, &so, 0,
+                          h->d_stats_stream.p + (size_t)g * 2 * h->cols, use_last);
+            if (rc != MFX_OK) return rc;
+        }
+    }
+    h->block_applied = true;
+    return MFX_OK;
+}
+
+extern "C" int mfx_get_output_data(mfx_handle *h, float *data_out, int32_t frames)
+{
+    if (!h || (!data_out && frames > 0) || frames < 0) return MFX_ERR_ARG;
+    if (frames > h->window_limit) return fail(h, MFX_ERR_WINDOW_HIGH, kMsgHigh);
+    if (frames == 0) return MFX_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(data_out, h->d_blk.p, sizeof(float) * (size_t)frames * h->width, hipMemcpyDeviceToHost,
+                              h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch interface
+// ------------------------------------------------------------------------------------------------
+
+extern "C" int64_t mfx_batch_frames(const mfx_handle *h, int64_t samples)
+{
+    if (!h) return MFX_ERR_ARG;
+    int64_t t = frame_count(samples, h->W, h->S);
+    return t > 0 ? t : 0;
+}
+
+extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offsets, const int64_t *lengths,
+                              int64_t *out_rows, int64_t *total_rows)
+{
+    if (!h || n_utt < 0 || (n_utt > 0 && (!offsets || !lengths))) return MFX_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->n_utt = n_utt;
+    h->utt_off.assign(offsets, offsets + n_utt);
+    h->utt_len.assign(lengths, lengths + n_utt);
+    h->utt_row.resize(n_utt);
+    h->h_chunks.clear();
+    std::vector<Segment> segs((size_t)n_utt);
+    int64_t row = 0;
+    int tiles_max = 0;
+    bool aligned = (h->S % 2) == 0;
+    for (int u = 0; u < n_utt; ++u) {
+        if (offsets[u] < 0 || lengths[u] < 0) return fail(h, MFX_ERR_ARG, "negative utterance offset/length");
+        int64_t T = frame_count(lengths[u], h->W, h->S);
+        if (T < 0) T = 0;
+        if (T > 0x7fffffff) return fail(h, MFX_ERR_ARG, "utterance too long");
+        h->utt_row[u] = row;
+        if (out_rows) out_rows[u] = row;
+        if (offsets[u] & 1) aligned = false;
+        for (int64_t t0 = 0; t0 < T; t0 += kChunkFrames) {
+            Chunk c;
+            c.pcm_off = offsets[u] + t0 * h->S;
+            c.out_row = row + t0;
+            c.n_frames = (int32_t)std::min<int64_t>(kChunkFrames, T - t0);
+            c.pad = 0;
+            h->h_chunks.push_back(c);
+        }
+        Segment &s = segs[u];
+        std::memset(&s, 0, sizeof(s));
+        s.src_row0 = row;
+        s.out_row0 = row;
+        s.n_out = (int32_t)T;
+        s.shift = -h->D; // whole utterance: D replicated rows on both sides
+        s.lo = 0;
+        s.hi = (int32_t)std::max<int64_t>(T - 1, 0);
+        s.static_off = 0;
+        tiles_max = std::max<int>(tiles_max, (int)((T + 63) / 64));
+        row += T;
+    }
+    h->total_rows = row;
+    h->tiles_max = tiles_max;
+    h->batch_aligned = aligned;
+    if (total_rows) *total_rows = row;
+    HIP_TRY(h, upload(h->d_chunks, h->h_chunks));
+    HIP_TRY(h, upload(h->d_segs, segs));
+    if (h->cfg.norm != MFX_NORM_NONE) HIP_TRY(h, h->d_stats_batch.alloc((size_t)n_utt * 3 * 2 * h->cols));
+    return MFX_OK;
+}
+
+extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_total, float *d_out)
+{
+    if (!h || !d_pcm || !d_out || pcm_samples_total <= 0) return MFX_ERR_ARG;
+    if (!h->have_window) return fail(h, MFX_ERR_STATE, "set_window has not been called");
+    if (h->total_rows == 0) return MFX_OK;
+    if (((uintptr_t)d_pcm & 3) != 0) return fail(h, MFX_ERR_ARG, "d_pcm must be 4-byte aligned");
+    for (int u = 0; u < h->n_utt; ++u)
+        if (h->utt_off[u] + h->utt_len[u] > pcm_samples_total)
+            return fail(h, MFX_ERR_ARG, "utterance extends past the end of the PCM array");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = refresh_mel(h);
+    if (rc != MFX_OK) return rc;
+
+    FrontParams p;
+    fill_front(h, p);
+    p.pcm = d_pcm;
+    p.pcm_total = pcm_samples_total * h->channels;
+    p.chunks = h->d_chunks.p;
+    p.n_chunks = (int32_t)h->h_chunks.size();
+    p.row_limit = h->total_rows;
+    p.feat = d_out;
+    p.feat_pitch = h->width;
+
+    if (h->fast512) {
+        ProfScope ps(h);
+        HIP_TRY(h, launch_front512(p, /*to_spectrum=*/false, h->batch_aligned, h->nm16, h->stream));
+    } else {
+        // generic sizes: magnitudes go through an HBM slab, then melcep
+        const int64_t slab_rows_max = 1 << 17;
+        const int64_t slab_rows = std::min<int64_t>(h->total_rows, slab_rows_max);
+        if (h->d_spec_slab.n < (size_t)slab_rows * h->spec_pitch)
+            HIP_TRY(h, h->d_spec_slab.alloc((size_t)slab_rows * h->spec_pitch));
+        size_t c0 = 0;
+        const size_t nchunks = h->h_chunks.size();
+        while (c0 < nchunks) {
+            const int64_t row0 = h->h_chunks[c0].out_row;
+            size_t c1 = c0;
+            int64_t rows = 0;
+            while (c1 < nchunks && rows + h->h_chunks[c1].n_frames <= slab_rows) {
+                rows += h->h_chunks[c1].n_frames;
+                ++c1;
+            }
+            FrontParams q = p;
+            q.chunks = h->d_chunks.p + c0;
+            q.n_chunks = (int32_t)(c1 - c0);
+            q.spec = h->d_spec_slab.p - row0 * (int64_t)h->spec_pitch; // rows are addressed absolutely
+            q.spec_pitch = h->spec_pitch;
+            {
+                ProfScope ps(h);
+                HIP_TRY(h, launch_front_generic(q, h->stream));
+            }
+            MelcepParams mp;
+            std::memset(&mp, 0, sizeof(mp));
+            mp.spec = h->d_spec_slab.p;
+            mp.spec_pitch = h->spec_pitch;
+            mp.n_rows = rows;
+            mp.feat = d_out + row0 * (int64_t)h->width;
+            mp.feat_pitch = h->width;
+            mp.fft_size = h->W2;
+            mp.mel_w = h->d_mel_w.p;
+            mp.mel_beg = h->d_mel_beg.p;
+            mp.dct = h->ceps > 0 ? h->d_dct.p : nullptr;
+            mp.num_banks = h->nb;
+            mp.dct_len = h->dl;
+            mp.cols = h->cols;
+            HIP_TRY(h, launch_melcep(mp, h->stream));
+            c0 = c1;
+        }
+    }
+
+    const bool norm = h->cfg.norm != MFX_NORM_NONE;
+    if (norm && !h->cfg.norm_after_dyn) {
+        rc = run_norm(h, d_out, h->width, 0, h->d_segs.p, h->n_utt, nullptr, 0, h->d_stats_batch.p, false);
+        if (rc != MFX_OK) return rc;
+    }
+    if (h->l1 > 0) {
+        DeltaParams dp;
+        std::memset(&dp, 0, sizeof(dp));
+        dp.src = d_out;
+        dp.src_pitch = h->width;
+        dp.out = d_out;
+        dp.out_pitch = h->width;
+        dp.segs = h->d_segs.p;
+        dp.n_segs = h->n_utt;
+        dp.cols = h->cols;
+        dp.l1 = h->l1;
+        dp.l2 = h->l2;
+        dp.tiles_per_seg_max = h->tiles_max;
+        HIP_TRY(h, launch_delta(dp, h->stream));
+    }
+    if (norm && h->cfg.norm_after_dyn) {
+        const int groups = h->width / h->cols;
+        for (int g = 0; g < groups; ++g) {
+            rc = run_norm(h, d_out, h->width, g * h->cols, h->d_segs.p, h->n_utt, nullptr, 0,
+                          h->d_stats_batch.p + (size_t)g * h->n_utt * 2 * h->cols, false);
+            if (rc != MFX_OK) return rc;
+        }
+    }
+    return MFX_OK;
+}
+
+extern "C" int mfx_batch_run_host(mfx_handle *h, const int16_t *pcm, int64_t pcm_samples_total, float *out)
+{
+    if (!h || !pcm || !out || pcm_samples_total <= 0) return MFX_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    DevBuf<int16_t> d_pcm;
+    DevBuf<float> d_out;
+    const size_t n_in = (size_t)pcm_samples_total * h->channels;
+    HIP_TRY(h, d_pcm.alloc(n_in + 8));
+    hipError_t e = d_out.alloc((size_t)std::max<int64_t>(h->total_rows, 1) * h->width);
+    if (e != hipSuccess) {
+        d_pcm.release();
+        return fail_hip(h, e, "hipMalloc(out)");
+    }
+    int rc = MFX_OK;
+    e = hipMemcpyAsync(d_pcm.p, pcm, n_in * sizeof(int16_t), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        rc = mfx_batch_run_device(h, d_pcm.p, pcm_samples_total, d_out.p);
+        if (rc == MFX_OK && h->total_rows > 0)
+            e = hipMemcpyAsync(out, d_out.p, (size_t)h->total_rows * h->width * sizeof(float), hipMemcpyDeviceToHost,
+                               h->stream);
+    }
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    d_pcm.release();
+    d_out.release();
+    if (rc != MFX_OK) return rc;
+    if (e != hipSuccess) return fail_hip(h, e, "batch copy");
+    if (e2 != hipSuccess) return fail_hip(h, e2, "hipStreamSynchronize");
+    return MFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// test taps
+// ------------------------------------------------------------------------------------------------
+
+extern "C" int64_t mfx_debug_read(mfx_handle *h, int kind, void *dst, int64_t dst_bytes)
+{
+    if (!h || !dst) return MFX_ERR_ARG;
+    if (hipSetDevice(h->device) != hipSuccess) return MFX_ERR_DEVICE;
+    const void *src = nullptr;
+    int64_t count = 0, esz = 4;
+    switch (kind) {
+    case 0:
+        if (refresh_mel(h) != MFX_OK) return MFX_ERR_DEVICE;
+        src = h->d_mel_w.p;
+        count = 2 * (int64_t)h->W2;
+        break;
+    case 1:
+        if (refresh_mel(h) != MFX_OK) return MFX_ERR_DEVICE;
+        src = h->d_mel_beg.p;
+        count = h->nb + 2;
+        break;
+    case 2:
+        src = h->d_dct.p;
+        count = h->ceps > 0 ? (int64_t)h->nb * h->dl : 0;
+        break;
+    case 3:
+        src = h->d_spec.p;
+        count = (int64_t)h->block_wcnd * h->spec_pitch;
+        break;
+    default:
+        return MFX_ERR_ARG;
+    }
+    if (count * esz > dst_bytes) return MFX_ERR_ARG;
+    if (count == 0) return 0;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return MFX_ERR_DEVICE;
+    if (hipMemcpy(dst, src, (size_t)(count * esz), hipMemcpyDeviceToHost) != hipSuccess) return MFX_ERR_DEVICE;
+    return count;
+}

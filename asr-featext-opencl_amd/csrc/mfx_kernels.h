@@ -1,0 +1,122 @@
+// mfx_kernels.h -- launch interface of the gfx950 kernels (implemented in mfx_kernels.hip).
+//
+// Kernel inventory and the reference stage each one replaces:
+//   spectrum512 / fused512   segmenter.cl kernelSegmentWindow + AppleFFT fft0 + mfcc.cl kernelTranspose
+//                            (+ mfcc.cl kernelFilter + the DCT slot when fused)
+//   spectrum_generic         same three stages for any power-of-two FFT length
+//   melcep                   mfcc.cl kernelFilter + DCT slot (mfccopencl.cpp:315-358) from a stored spectrum
+//   delta                    delta.cl kernelDelta x2 + the staging copies of mfccopencl.cpp:360-387
+//   norm_stats / norm_apply  norm.cl kernelSum + kernelFinalizeSum / kernelNormalize
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mfx {
+
+// A run of consecutive frames of one utterance (or of the streaming carry buffer).
+struct Chunk {
+    int64_t pcm_off;  // sample index (per channel) of the first sample of the chunk's first frame
+    int64_t out_row;  // destination row of the chunk's first frame
+    int32_t n_frames;
+    int32_t pad;
+};
+
+// One independent series of feature rows (an utterance, or the current streaming block) for the
+// delta and normalisation kernels.
+struct Segment {
+    int64_t src_row0;   // first row of the series inside the static-feature buffer
+    int64_t out_row0;   // first output row
+    int32_t n_out;      // rows to produce
+    int32_t shift;      // padded[i] = src[clamp(i + shift, lo, hi)] (rows relative to src_row0)
+    int32_t lo, hi;
+    int32_t static_off; // static part of output row r is src row r + static_off
+    int32_t pad;
+};
+
+struct FrontParams {
+    const int16_t *pcm;
+    int64_t pcm_total;        // int16 elements readable behind `pcm` (all channels)
+    const Chunk *chunks;
+    int32_t n_chunks;
+    int32_t channels;         // 1 or 2 (generic kernel only)
+    int64_t row_limit;        // frames whose destination row is >= row_limit are skipped
+    int32_t window_size;      // W
+    int32_t shift;            // S
+    int32_t fft_size;         // W2
+    // outputs: exactly one of {spec, feat} is used by a launch
+    float *spec;              // [rows][spec_pitch] magnitudes |X[k]|/W2, k = 0..W2/2
+    int32_t spec_pitch;
+    float *feat;              // [rows][feat_pitch], static features written at columns [0, cols)
+    int32_t feat_pitch;
+    // tables (device pointers)
+    const float *window;      // [W2] zero padded                      (generic)
+    const float *winpair;     // [16][16][2] window laid out per lane  (512 fast path)
+    const float *twid_pass;   // [16][16][2] W_256^(l*k)               (512 fast path)
+    const float *twid_half;   // [W2/4][2]   W_{W2/2}^k                (generic Stockham)
+    const float *twid_split;  // [W2/2+1][2] -i * W_{W2}^k             (real split)
+    const float *mel_w;       // [2][W2]
+    const int32_t *mel_beg;   // [nb+2]
+    const float *dct;         // [nb][dct_len] or nullptr when ceps_len == 0
+    int32_t num_banks;
+    int32_t dct_len;
+    int32_t cols;             // dct_len, or num_banks when ceps_len == 0
+    float scale;              // 1/W2 (0.5/W2 where the split's 1/2 is folded in)
+};
+
+struct MelcepParams {
+    const float *spec;
+    int32_t spec_pitch;
+    int64_t n_rows;
+    float *feat;
+    int32_t feat_pitch;
+    int32_t fft_size;
+    const float *mel_w;
+    const int32_t *mel_beg;
+    const float *dct;
+    int32_t num_banks, dct_len, cols;
+};
+
+struct DeltaParams {
+    const float *src;      // static features, [rows][src_pitch]
+    int32_t src_pitch;
+    float *out;            // [rows][out_pitch]: [static | delta | acc]
+    int32_t out_pitch;
+    const Segment *segs;
+    int32_t n_segs;
+    int32_t cols;
+    int32_t l1, l2;        // l2 == 0: first order only; l1 == 0: copy statics only
+    int32_t tiles_per_seg_max;
+    int32_t inline_seg;    // nonzero: ignore segs and use seg0 (single streaming block)
+    Segment seg0;
+};
+
+struct NormParams {
+    float *data;           // [rows][pitch], normalised in place at column offset col0
+    int32_t pitch;
+    int32_t col0;
+    int32_t cols;
+    const Segment *segs;   // uses out_row0 / n_out (rows to normalise) only
+    int32_t n_segs;
+    int32_t row_off;       // extra row offset added to out_row0
+    int32_t norm_type;     // MFX_NORM_*
+    float *stats;          // [n_segs][2][cols]: mean, scale (persist across calls for use_last_stats)
+    int32_t inline_seg;    // nonzero: ignore segs and use seg0
+    Segment seg0;
+};
+
+// All launchers are asynchronous on `stream` and return the launch status.
+hipError_t launch_front512(const FrontParams &p, bool to_spectrum, bool aligned, int nm16, hipStream_t stream);
+hipError_t launch_front_generic(const FrontParams &p, hipStream_t stream);
+hipError_t launch_melcep(const MelcepParams &p, hipStream_t stream);
+hipError_t launch_delta(const DeltaParams &p, hipStream_t stream);
+hipError_t launch_norm_stats(const NormParams &p, hipStream_t stream);
+hipError_t launch_norm_apply(const NormParams &p, hipStream_t stream);
+
+// true when the 512-point fast path can take this configuration
+bool front512_supported(int fft_size, int window_size, int num_banks, int cols, int channels);
+
+// symbol name of the dominant kernel for rocprofv3 (depends on the instantiation chosen)
+const char *front512_kernel_name(bool to_spectrum, bool aligned, int nm16);
+
+} // namespace mfx

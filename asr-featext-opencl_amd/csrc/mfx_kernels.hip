@@ -1,0 +1,658 @@
+// mfx_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the MFCC front end.  See mfx_kernels.h
+// for the inventory and DESIGN.md for the data layout and the roofline of each kernel.
+//
+// Numerics follow the reference CPU path (mfcccpu.cpp): frames = window * int16 sample (one
+// rounding), unnormalised forward DFT, magnitude / W2, two-row triangular mel table walked in
+// ascending bin order, log(max(., 1e-30)), DCT as a k-ordered dot product.
+#include "mfx_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace mfx {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+
+// All cross-lane traffic inside a wave goes through LDS instructions of that same wave, which the
+// LDS executes in issue order; only the compiler has to be kept from reordering around it.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 w)
+{
+    return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+}
+
+// 4-point forward DFT (W4 = -i)
+__device__ __forceinline__ void dft4(float2 a0, float2 a1, float2 a2, float2 a3, float2 &o0, float2 &o1,
+                                     float2 &o2, float2 &o3)
+{
+    float2 b0 = make_float2(a0.x + a2.x, a0.y + a2.y);
+    float2 b1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+    float2 b2 = make_float2(a1.x + a3.x, a1.y + a3.y);
+    float2 b3 = make_float2(a1.x - a3.x, a1.y - a3.y);
+    o0 = make_float2(b0.x + b2.x, b0.y + b2.y);
+    o2 = make_float2(b0.x - b2.x, b0.y - b2.y);
+    o1 = make_float2(b1.x + b3.y, b1.y - b3.x); // b1 - i*b3
+    o3 = make_float2(b1.x - b3.y, b1.y + b3.x); // b1 + i*b3
+}
+
+// 16-point forward DFT held entirely in registers, natural order in and out (4 x 4 Cooley-Tukey).
+// Inputs that are compile-time zeros are folded away by the compiler after inlining.
+__device__ __forceinline__ void fft16(float2 (&x)[16])
+{
+    constexpr float C1 = 0.92387953251128673848f; // cos(pi/8)
+    constexpr float S1 = 0.38268343236508978178f; // sin(pi/8)
+    constexpr float R = 0.70710678118654752440f;  // sqrt(1/2)
+    float2 y[16];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2)
+        dft4(x[n2], x[4 + n2], x[8 + n2], x[12 + n2], y[0 + n2], y[4 + n2], y[8 + n2], y[12 + n2]);
+    // y[4*k1 + n2] *= W16^(n2*k1)
+    float2 t;
+    t = y[4 + 1];  y[4 + 1]  = make_float2(t.x * C1 + t.y * S1, t.y * C1 - t.x * S1);     // W^1
+    t = y[4 + 2];  y[4 + 2]  = make_float2(R * (t.x + t.y), R * (t.y - t.x));             // W^2
+    t = y[4 + 3];  y[4 + 3]  = make_float2(t.x * S1 + t.y * C1, t.y * S1 - t.x * C1);     // W^3
+    t = y[8 + 1];  y[8 + 1]  = make_float2(R * (t.x + t.y), R * (t.y - t.x));             // W^2
+    t = y[8 + 2];  y[8 + 2]  = make_float2(t.y, -t.x);                                    // W^4
+    t = y[8 + 3];  y[8 + 3]  = make_float2(R * (t.y - t.x), -R * (t.x + t.y));            // W^6
+    t = y[12 + 1]; y[12 + 1] = make_float2(t.x * S1 + t.y * C1, t.y * S1 - t.x * C1);     // W^3
+    t = y[12 + 2]; y[12 + 2] = make_float2(R * (t.y - t.x), -R * (t.x + t.y));            // W^6
+    t = y[12 + 3]; y[12 + 3] = make_float2(-(t.x * C1 + t.y * S1), t.x * S1 - t.y * C1);  // W^9
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1)
+        dft4(y[4 * k1], y[4 * k1 + 1], y[4 * k1 + 2], y[4 * k1 + 3], x[k1], x[k1 + 4], x[k1 + 8], x[k1 + 12]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// mel filterbank + log + DCT for ONE frame whose magnitudes sit in LDS, shared by G lanes.
+//   mag     : LDS, bins 0..W2/2 of this frame
+//   melbuf  : LDS scratch, >= num_banks floats, private to this frame's lane group
+//   g       : lane index inside the group [0, G)
+// Filter m = sum over bins [beg[m], beg[m+2]) of w[m & 1][bin] * mag[bin] in ascending bin order
+// (mfcccpu.cpp:192-220, `while` semantics for coincident edges); out[c] = sum_m mel[m]*dct[m][c] in
+// ascending m (mfcccpu.cpp:222-232).  Tables are read from LDS copies (s_*).
+// ------------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int g, const float *s_w0,
+                                            const float *s_w1, const int *s_beg, const float *s_dct, int nb,
+                                            int dct_len, int cols, float *out_row)
+{
+    for (int m = g; m < nb; m += G) {
+        const int b0 = s_beg[m], b1 = s_beg[m + 2];
+        const float *w = (m & 1) ? s_w1 : s_w0;
+        float acc = 0.f;
+        for (int k = b0; k < b1; ++k) acc += w[k] * mag[k];
+        melbuf[m] = logf(fmaxf(acc, 1e-30f));
+    }
+    wave_sync();
+    if (s_dct) {
+        for (int c = g; c < cols; c += G) {
+            float acc = 0.f;
+            for (int m = 0; m < nb; ++m) acc += melbuf[m] * s_dct[m * dct_len + c];
+            out_row[c] = acc;
+        }
+    } else {
+        for (int c = g; c < cols; c += G) out_row[c] = melbuf[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 512-point front end.  One wave owns 4 frames per iteration, 16 lanes per frame.
+//
+//   real 512-point DFT of a frame = complex 256-point DFT of z[n] = x[2n] + i x[2n+1] + real split
+//   256 = 16 x 16:   lane l  : 16-point DFT over m of z[l + 16m]        (registers)
+//                    twiddle : * W_256^(l*k1)                            (per-lane constants)
+//                    LDS     : 16x16 transpose inside the frame's lane group
+//                    lane q  : 16-point DFT over l -> Z[q + 16p], p = 0..15
+//   split:  X[k] = 1/2 * ((Z[k] + conj Z[256-k]) + (-i W_512^k)(Z[k] - conj Z[256-k]))
+//           the partner Z[256-k] lives in lane (16-q)%16 of the same 16-lane row
+//   |X[k]| / 512 -> LDS (or HBM when TO_SPEC), then mel/log/DCT on the 16 lanes of the frame.
+//
+// LDS per frame slot: 16 rows x 34 dwords (row = 16 complex + 2 dwords pad: the b64 transpose
+// reads then hit 32 distinct bank pairs per half wave); the magnitudes and the mel scratch reuse
+// the same slot once the transpose has been consumed.
+// ------------------------------------------------------------------------------------------------
+constexpr int kXRow = 34;            // dwords per transpose row
+constexpr int kXFrame = 16 * kXRow;  // 544 dwords per frame slot
+constexpr int kMelOff = 272;         // mel scratch offset inside the slot (after 257 magnitudes)
+constexpr int kBinsPad = 264;        // padded length of the LDS mel-weight rows (257 used)
+
+template <bool ALIGNED, bool TO_SPEC, int NM>
+__global__ void __launch_bounds__(256) k_front512(FrontParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int slot = lane >> 4, l = lane & 15;
+
+    // ---- LDS carve: shared tables, then one 4-slot region per wave
+    const int nb = p.num_banks, dl = p.dct_len, cols = p.cols;
+    float *s_w0 = smem;
+    float *s_w1 = s_w0 + kBinsPad;
+    float *s_split = s_w1 + kBinsPad;            // [264][2]
+    int *s_beg = (int *)(s_split + 2 * kBinsPad);
+    const int beg_pad = (nb + 2 + 3) & ~3;
+    float *s_dct = (float *)(s_beg + beg_pad);
+    const int dct_floats = (p.dct ? nb * dl : 0);
+    const int dct_pad = (dct_floats + 3) & ~3;
+    float *s_wave = s_dct + dct_pad + wave * (4 * kXFrame);
+    float *xb = s_wave + slot * kXFrame;
+
+    if (!TO_SPEC) {
+        for (int i = tid; i < 257; i += 256) {
+            s_w0[i] = p.mel_w[i];
+            s_w1[i] = p.mel_w[512 + i];
+        }
+        for (int i = tid; i < nb + 2; i += 256) s_beg[i] = p.mel_beg[i];
+        for (int i = tid; i < dct_floats; i += 256) s_dct[i] = p.dct[i];
+    }
+    for (int i = tid; i < 2 * 257; i += 256) s_split[i] = p.twid_split[i];
+    __syncthreads();
+
+    // ---- per-lane constants kept in registers for the whole kernel
+    float2 win[NM], tw[16];
+    {
+        const float2 *wp = (const float2 *)p.winpair + l * 16;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) win[m] = wp[m];
+        const float2 *tp = (const float2 *)p.twid_pass + l * 16;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tw[k] = tp[k];
+    }
+    const uint32_t *pcm32 = (const uint32_t *)p.pcm;
+    const int64_t max_idx = (p.pcm_total - 1) >> 1;
+    const float scale = p.scale;
+    const int partner = (lane & 48) | ((16 - l) & 15);
+
+    for (int c = blockIdx.x * 4 + wave; c < p.n_chunks; c += gridDim.x * 4) {
+        const Chunk ch = p.chunks[c];
+        for (int f0 = 0; f0 < ch.n_frames; f0 += 4) {
+            const int f = f0 + slot;
+            const bool live = f < ch.n_frames && (ch.out_row + f) < p.row_limit;
+            const int64_t s0 = ch.pcm_off + (int64_t)(live ? f : 0) * p.shift;
+
+            // ---- framing + window: z[l + 16m] = (w[2n] x[2n], w[2n+1] x[2n+1])
+            float2 a[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                if (m < NM) {
+                    uint32_t d;
+                    if (ALIGNED) {
+                        int64_t idx = (s0 >> 1) + l + 16 * m;
+                        idx = idx < max_idx ? idx : max_idx;
+                        d = pcm32[idx];
+                    } else {
+                        int64_t s = s0 + 2 * (l + 16 * m);
+                        int64_t i0 = s >> 1;
+                        int64_t i1 = i0 + 1;
+                        i0 = i0 < max_idx ? i0 : max_idx;
+                        i1 = i1 < max_idx ? i1 : max_idx;
+                        uint32_t d0 = pcm32[i0], d1 = pcm32[i1];
+                        d = (s & 1) ? ((d0 >> 16) | (d1 << 16)) : d0;
+                    }
+                    float x0 = (float)(int)(short)(d & 0xffffu);
+                    float x1 = (float)((int)d >> 16);
+                    a[m] = make_float2(win[m].x * x0, win[m].y * x1);
+                } else {
+                    a[m] = make_float2(0.f, 0.f);
+                }
+            }
+
+            // ---- pass A + inter-pass twiddle
+            fft16(a);
+#pragma unroll
+            for (int k = 1; k < 16; ++k) a[k] = cmul(a[k], tw[k]);
+
+            // ---- 16x16 transpose through the frame slot
+#pragma unroll
+            for (int k = 0; k < 16; ++k) ((float2 *)(xb + k * kXRow))[l] = a[k];
+            wave_sync();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[j] = ((const float2 *)(xb + l * kXRow))[j];
+            wave_sync();
+
+            // ---- pass B: a[pp] = Z[l + 16 pp]
+            fft16(a);
+
+            // ---- real split + magnitude
+            float mag[16];
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp) {
+                // partner value Z[256 - k]: lane (16-l)%16, register 15-pp (lane 0: register (16-pp)%16)
+                float zr = __shfl(a[15 - pp].x, partner, 64);
+                float zi = __shfl(a[15 - pp].y, partner, 64);
+                if (l == 0) {
+                    zr = a[(16 - pp) & 15].x;
+                    zi = a[(16 - pp) & 15].y;
+                }
+                const float2 cs = ((const float2 *)s_split)[l + 16 * pp];
+                const float sr = a[pp].x + zr, si = a[pp].y - zi;
+                const float dr = a[pp].x - zr, di = a[pp].y + zi;
+                const float xr = sr + (cs.x * dr - cs.y * di);
+                const float xi = si + (cs.x * di + cs.y * dr);
+                mag[pp] = sqrtf(xr * xr + xi * xi) * scale;
+            }
+            // Nyquist bin: X[256] = Re Z[0] - Im Z[0]
+            const float nyq = fabsf(a[0].x - a[0].y) * (2.0f * scale);
+
+            if (TO_SPEC) {
+                if (live) {
+                    float *dst = p.spec + (ch.out_row + f) * (int64_t)p.spec_pitch;
+#pragma unroll
+                    for (int pp = 0; pp < 16; ++pp) dst[l + 16 * pp] = mag[pp];
+                    if (l == 0) dst[256] = nyq;
+                }
+            } else {
+#pragma unroll
+                for (int pp = 0; pp < 16; ++pp) xb[l + 16 * pp] = mag[pp];
+                if (l == 0) xb[256] = nyq;
+                wave_sync();
+                // out_row pointer is only dereferenced by live frames
+                float *dst = p.feat + (ch.out_row + (live ? f : 0)) * (int64_t)p.feat_pitch;
+                float *melbuf = xb + kMelOff;
+                // every lane runs the mel loops (uniform control flow for wave_sync); dead slots
+                // write to a scratch row inside the slot instead of HBM
+                mel_log_dct<16>(xb, melbuf, l, s_w0, s_w1, s_beg, p.dct ? s_dct : nullptr, nb, dl, cols,
+                                live ? dst : (xb + kMelOff + 136));
+                wave_sync();
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic front end: any power-of-two FFT length 64..4096, mono or stereo, any alignment.
+// One 256-thread block per frame at a time (grid-stride over the frames of its chunks):
+// half-size complex Stockham radix-2 in LDS + real split; magnitudes to HBM.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_front_generic(FrontParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int W2 = p.fft_size, M = W2 >> 1;
+    float2 *bufA = (float2 *)smem;
+    float2 *bufB = bufA + M;
+    const float2 *tw = (const float2 *)p.twid_half;   // W_M^k, k < M/2
+    const float2 *cs = (const float2 *)p.twid_split;  // -i W_{W2}^k, k <= M
+    const int ch_n = p.channels;
+
+    for (int c = blockIdx.x; c < p.n_chunks; c += gridDim.x) {
+        const Chunk ch = p.chunks[c];
+        for (int f = 0; f < ch.n_frames && (ch.out_row + f) < p.row_limit; ++f) {
+            const int64_t s0 = ch.pcm_off + (int64_t)f * p.shift;
+            for (int n = tid; n < M; n += 256) {
+                float v[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int j = 2 * n + e;
+                    float x = 0.f;
+                    if (j < p.window_size) {
+                        const int64_t s = s0 + j;
+                        int xi;
+                        if (ch_n == 2) {
+                            // stereo -> mono (L + R) >> 1 in integer arithmetic
+                            xi = ((int)p.pcm[2 * s] + (int)p.pcm[2 * s + 1]) >> 1;
+                        } else {
+                            xi = (int)p.pcm[s];
+                        }
+                        x = p.window[j] * (float)xi;
+                    }
+                    v[e] = x;
+                }
+                bufA[n] = make_float2(v[0], v[1]);
+            }
+            __syncthreads();
+            float2 *x = bufA, *y = bufB;
+            for (int n = M, st = 1; n > 1; n >>= 1, st <<= 1) {
+                const int m = n >> 1;
+                const int tstep = M / n;
+                for (int idx = tid; idx < (M >> 1); idx += 256) {
+                    const int pp = idx / st, q = idx - pp * st;
+                    const float2 w = tw[pp * tstep];
+                    const float2 a = x[q + st * pp], b = x[q + st * (pp + m)];
+                    y[q + st * (2 * pp)] = make_float2(a.x + b.x, a.y + b.y);
+                    y[q + st * (2 * pp + 1)] = cmul(make_float2(a.x - b.x, a.y - b.y), w);
+                }
+                __syncthreads();
+                float2 *t = x;
+                x = y;
+                y = t;
+            }
+            float *dst = p.spec + (ch.out_row + f) * (int64_t)p.spec_pitch;
+            const float scale = p.scale; // 0.5 / W2
+            for (int k = tid; k <= M; k += 256) {
+                const float2 zk = x[k & (M - 1)];
+                const float2 zm = x[(M - k) & (M - 1)];
+                const float sr = zk.x + zm.x, si = zk.y - zm.y;
+                const float dr = zk.x - zm.x, di = zk.y + zm.y;
+                const float2 w = cs[k];
+                const float xr = sr + (w.x * dr - w.y * di);
+                const float xi = si + (w.x * di + w.y * dr);
+                dst[k] = sqrtf(xr * xr + xi * xi) * scale;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// melcep: stored magnitudes -> mel -> log -> DCT.  One wave per frame, 4 waves per block.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_melcep(MelcepParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int W2 = p.fft_size, nbins = (W2 >> 1) + 1;
+    const int bins_pad = (nbins + 3) & ~3;
+    const int nb = p.num_banks, dl = p.dct_len;
+    float *s_w0 = smem;
+    float *s_w1 = s_w0 + bins_pad;
+    int *s_beg = (int *)(s_w1 + bins_pad);
+    const int beg_pad = (nb + 2 + 3) & ~3;
+    float *s_dct = (float *)(s_beg + beg_pad);
+    const int dct_floats = p.dct ? nb * dl : 0;
+    const int dct_pad = (dct_floats + 3) & ~3;
+    const int nb_pad = (nb + 3) & ~3;
+    float *s_mag = s_dct + dct_pad + wave * (bins_pad + nb_pad);
+    float *s_mel = s_mag + bins_pad;
+
+    for (int i = tid; i < nbins; i += 256) {
+        s_w0[i] = p.mel_w[i];
+        s_w1[i] = p.mel_w[W2 + i];
+    }
+    for (int i = tid; i < nb + 2; i += 256) s_beg[i] = p.mel_beg[i];
+    for (int i = tid; i < dct_floats; i += 256) s_dct[i] = p.dct[i];
+    __syncthreads();
+
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < p.n_rows; r += (int64_t)gridDim.x * 4) {
+        const float *src = p.spec + r * p.spec_pitch;
+        for (int k = lane; k < nbins; k += 64) s_mag[k] = src[k];
+        wave_sync();
+        mel_log_dct<64>(s_mag, s_mel, lane, s_w0, s_w1, s_beg, p.dct ? s_dct : nullptr, nb, dl, p.cols,
+                        p.feat + r * p.feat_pitch);
+        wave_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// delta: regression coefficients over time (deltacpu.cpp:16-29) with the edge handling of
+// MfccCpu::do_delta (mfcccpu.cpp:234-263) expressed as a clamped row accessor (Segment).
+// grid = (tiles, segments); one tile = kDeltaRows output rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int kDeltaRows = 64;
+
+__global__ void __launch_bounds__(256) k_delta(DeltaParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Segment sg = p.inline_seg ? p.seg0 : p.segs[blockIdx.y];
+    const int r0 = blockIdx.x * kDeltaRows;
+    if (r0 >= sg.n_out) return;
+    const int rows = min(kDeltaRows, sg.n_out - r0);
+    const int cols = p.cols, l1 = p.l1, l2 = p.l2, D = l1 + l2;
+    const int tid = threadIdx.x;
+    float *s_pad = smem;                               // [rows + 2D][cols]
+    float *s_d = smem + (kDeltaRows + 2 * D) * cols;   // [rows + 2*l2][cols]
+
+    if (l1 > 0) {
+        const int n_pad = (rows + 2 * D) * cols;
+        for (int i = tid; i < n_pad; i += 256) {
+            const int rr = i / cols, c = i - rr * cols;
+            int sr = r0 + rr + sg.shift;
+            sr = max(sg.lo, min(sg.hi, sr));
+            s_pad[i] = p.src[(sg.src_row0 + sr) * (int64_t)p.src_pitch + c];
+        }
+        __syncthreads();
+        float den = 0.f;
+        for (int l = 1; l <= l1; ++l) den += (float)(l * l);
+        const int n_d = (rows + 2 * l2) * cols;
+        for (int i = tid; i < n_d; i += 256) {
+            const int rr = i / cols, c = i - rr * cols;
+            float num = 0.f;
+            for (int l = 1; l <= l1; ++l)
+                num += (float)l * (s_pad[(rr + l1 + l) * cols + c] - s_pad[(rr + l1 - l) * cols + c]);
+            s_d[i] = num / (2 * den);
+        }
+        __syncthreads();
+    }
+    float den2 = 0.f;
+    for (int l = 1; l <= l2; ++l) den2 += (float)(l * l);
+    const bool in_place = (p.src == p.out) && (sg.src_row0 + sg.static_off == sg.out_row0) && (p.src_pitch == p.out_pitch);
+    const int n_o = rows * cols;
+    for (int i = tid; i < n_o; i += 256) {
+        const int rr = i / cols, c = i - rr * cols;
+        float *orow = p.out + (sg.out_row0 + r0 + rr) * (int64_t)p.out_pitch;
+        if (!in_place)
+            orow[c] = p.src[(sg.src_row0 + r0 + rr + sg.static_off) * (int64_t)p.src_pitch + c];
+        if (l1 > 0) {
+            orow[cols + c] = s_d[(rr + l2) * cols + c];
+            if (l2 > 0) {
+                float num = 0.f;
+                for (int l = 1; l <= l2; ++l)
+                    num += (float)l * (s_d[(rr + l2 + l) * cols + c] - s_d[(rr + l2 - l) * cols + c]);
+                orow[2 * cols + c] = num / (2 * den2);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// normalisation (normalizercpu.cpp:22-89): per segment, per column statistics in double.
+// stats layout [seg][2][cols]: mean, multiplier.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_norm_stats(NormParams p)
+{
+    __shared__ double s_sum[256], s_sum2[256];
+    __shared__ float s_min[256], s_max[256];
+    const Segment sg = p.inline_seg ? p.seg0 : p.segs[blockIdx.y];
+    const int c = blockIdx.x; // one block per (column, segment)
+    const int n = sg.n_out;
+    const float *base = p.data + (sg.out_row0 + p.row_off) * (int64_t)p.pitch + p.col0 + c;
+    double sum = 0, sum2 = 0;
+    float mn = 3.402823466e+38f, mx = -3.402823466e+38f;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        const float v = base[(int64_t)r * p.pitch];
+        sum += v;
+        sum2 += (double)(v * v);
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    s_sum[threadIdx.x] = sum;
+    s_sum2[threadIdx.x] = sum2;
+    s_min[threadIdx.x] = mn;
+    s_max[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            s_sum[threadIdx.x] += s_sum[threadIdx.x + s];
+            s_sum2[threadIdx.x] += s_sum2[threadIdx.x + s];
+            s_min[threadIdx.x] = fminf(s_min[threadIdx.x], s_min[threadIdx.x + s]);
+            s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double S = s_sum[0], S2 = s_sum2[0];
+        const float mean = (float)(S / n);
+        float mult = 1.f;
+        if (p.norm_type == 2)
+            mult = (float)sqrt((n - 1) / (S2 - S * (S / n)));
+        else if (p.norm_type == 3)
+            mult = 1.f / fmaxf(fabsf(s_min[0] - mean), fabsf(s_max[0] - mean));
+        float *st = p.stats + (int64_t)blockIdx.y * 2 * p.cols;
+        st[c] = mean;
+        st[p.cols + c] = mult;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_norm_apply(NormParams p)
+{
+    const Segment sg = p.inline_seg ? p.seg0 : p.segs[blockIdx.y];
+    const int cols = p.cols;
+    const int64_t total = (int64_t)sg.n_out * cols;
+    const float *st = p.stats + (int64_t)blockIdx.y * 2 * cols;
+    float *base = p.data + (sg.out_row0 + p.row_off) * (int64_t)p.pitch + p.col0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        float *q = base + r * p.pitch + c;
+        const float v = *q;
+        if (p.norm_type == 1)
+            *q = v - st[c];
+        else
+            *q = (v - st[c]) * st[cols + c];
+    }
+}
+
+int g_num_cus = 0;
+int num_cus()
+{
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_num_cus = prop.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+size_t front512_lds_bytes(const FrontParams &p)
+{
+    const int nb = p.num_banks;
+    size_t f = 2 * kBinsPad + 2 * kBinsPad;             // mel rows + split twiddles
+    f += (nb + 2 + 3) & ~3;                              // beg
+    f += ((p.dct ? nb * p.dct_len : 0) + 3) & ~3;        // dct
+    f += 4 * 4 * kXFrame;                                // 4 waves x 4 frame slots
+    return f * sizeof(float);
+}
+
+template <bool A, bool S, int NM>
+hipError_t launch512(const FrontParams &p, hipStream_t stream)
+{
+    const size_t lds = front512_lds_bytes(p);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_front512<A, S, NM>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    int blocks = (p.n_chunks + 3) / 4;
+    const int cap = num_cus() * 4;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((k_front512<A, S, NM>), dim3(blocks), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace
+
+bool front512_supported(int fft_size, int window_size, int num_banks, int cols, int channels)
+{
+    return fft_size == 512 && window_size <= 512 && window_size > 0 && channels <= 1 && num_banks >= 1 &&
+           num_banks <= 128 && cols <= 128;
+}
+
+const char *front512_kernel_name(bool to_spectrum, bool aligned, int nm16)
+{
+    (void)to_spectrum;
+    (void)aligned;
+    (void)nm16;
+    return "k_front512";
+}
+
+hipError_t launch_front512(const FrontParams &p, bool to_spectrum, bool aligned, int nm16, hipStream_t stream)
+{
+    if (p.n_chunks <= 0) return hipSuccess;
+    // NM = number of 32-sample rows that carry window taps: 13 covers W <= 416 (25 ms at 16 kHz)
+    const bool nm13 = nm16 <= 13;
+    if (to_spectrum) {
+        if (aligned) return nm13 ? launch512<true, true, 13>(p, stream) : launch512<true, true, 16>(p, stream);
+        return nm13 ? launch512<false, true, 13>(p, stream) : launch512<false, true, 16>(p, stream);
+    }
+    if (aligned) return nm13 ? launch512<true, false, 13>(p, stream) : launch512<true, false, 16>(p, stream);
+    return nm13 ? launch512<false, false, 13>(p, stream) : launch512<false, false, 16>(p, stream);
+}
+
+hipError_t launch_front_generic(const FrontParams &p, hipStream_t stream)
+{
+    if (p.n_chunks <= 0) return hipSuccess;
+    const size_t lds = (size_t)p.fft_size * 2 * sizeof(float); // two buffers of W2/2 complex
+    int blocks = p.n_chunks;
+    const int cap = num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_front_generic, dim3(blocks), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_melcep(const MelcepParams &p, hipStream_t stream)
+{
+    if (p.n_rows <= 0) return hipSuccess;
+    const int nbins = (p.fft_size >> 1) + 1, bins_pad = (nbins + 3) & ~3;
+    const int nb = p.num_banks;
+    size_t f = 2 * bins_pad + ((nb + 2 + 3) & ~3) + (((p.dct ? nb * p.dct_len : 0) + 3) & ~3) +
+               4 * (bins_pad + ((nb + 3) & ~3));
+    const size_t lds = f * sizeof(float);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_melcep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    int64_t blocks = (p.n_rows + 3) / 4;
+    const int cap = num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_melcep, dim3((unsigned)blocks), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_delta(const DeltaParams &p, hipStream_t stream)
+{
+    if (p.n_segs <= 0 || p.tiles_per_seg_max <= 0) return hipSuccess;
+    const int D = p.l1 + p.l2;
+    const size_t lds = (size_t)((kDeltaRows + 2 * D) + (kDeltaRows + 2 * p.l2)) * p.cols * sizeof(float);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_delta, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    // grid.y is limited to 65535: split the segment list
+    for (int s0 = 0; s0 < p.n_segs; s0 += 65535) {
+        DeltaParams q = p;
+        q.segs = p.segs + s0;
+        q.n_segs = (p.n_segs - s0) < 65535 ? (p.n_segs - s0) : 65535;
+        hipLaunchKernelGGL(k_delta, dim3(p.tiles_per_seg_max, q.n_segs), dim3(256), lds, stream, q);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_norm_stats(const NormParams &p, hipStream_t stream)
+{
+    if (p.n_segs <= 0) return hipSuccess;
+    for (int s0 = 0; s0 < p.n_segs; s0 += 65535) {
+        NormParams q = p;
+        q.segs = p.segs + s0;
+        q.stats = p.stats + (int64_t)s0 * 2 * p.cols;
+        q.n_segs = (p.n_segs - s0) < 65535 ? (p.n_segs - s0) : 65535;
+        hipLaunchKernelGGL(k_norm_stats, dim3(p.cols, q.n_segs), dim3(256), 0, stream, q);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_norm_apply(const NormParams &p, hipStream_t stream)
+{
+    if (p.n_segs <= 0) return hipSuccess;
+    for (int s0 = 0; s0 < p.n_segs; s0 += 65535) {
+        NormParams q = p;
+        q.segs = p.segs + s0;
+        q.stats = p.stats + (int64_t)s0 * 2 * p.cols;
+        q.n_segs = (p.n_segs - s0) < 65535 ? (p.n_segs - s0) : 65535;
+        hipLaunchKernelGGL(k_norm_apply, dim3(8, q.n_segs), dim3(256), 0, stream, q);
+    }
+    return hipGetLastError();
+}
+
+} // namespace mfx

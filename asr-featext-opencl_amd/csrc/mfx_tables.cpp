@@ -1,0 +1,101 @@
+// mfx_tables.cpp -- see mfx_tables.h.  Compiled with -ffp-contract=off so that the float32
+// expression order below is what actually executes.
+#include "mfx_tables.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace mfx {
+
+static const float kPiF = (float)3.14159265358979323846264338;
+
+uint32_t ceil_pow2(uint32_t v)
+{
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+int64_t frame_count(int64_t samples, int window_size, int shift)
+{
+    int64_t num = samples - (int64_t)(window_size - shift);
+    // floor division (num may be negative for very short inputs)
+    int64_t q = num / shift;
+    if ((num % shift != 0) && ((num < 0) != (shift < 0))) --q;
+    return q;
+}
+
+int estimated_window_count_f32(int samples, int window_size, int shift)
+{
+    return (int)std::floor((float)(samples - (window_size - shift)) / (float)shift);
+}
+
+namespace {
+inline float mel_of_hz(float f) { return 1127 * std::log(f / 700 + 1); }  // float overloads
+inline float hz_of_mel(float m) { return 700 * (std::exp(m / 1127) - 1); }
+inline int round_bin(float centre_hz, int fft_size, float sample_rate)
+{
+    // reference: floor(c * W2 / sr + 0.5) with the sum taken in double (mfcccpu.cpp:40,47-49)
+    return (int)std::floor((double)(centre_hz * fft_size / sample_rate) + 0.5);
+}
+} // namespace
+
+void build_mel_table(int num_banks, int fft_size, float sample_rate, float low_freq, float high_freq,
+                     float alpha, MelTable &out)
+{
+    const int npts = num_banks + 2;
+    std::vector<float> centre(npts);
+    out.weights.assign((size_t)2 * fft_size, 0.0f);
+    out.beg.assign(npts, 0);
+
+    const float mel_lo = mel_of_hz(low_freq), mel_hi = mel_of_hz(high_freq);
+    const float one_minus_alpha = 1 - alpha;
+    for (int i = 0; i < npts; ++i) {
+        float hz = hz_of_mel(i / float(num_banks + 1) * (mel_hi - mel_lo) + mel_lo);
+        float omega = 2 * kPiF * hz / sample_rate;
+        // VTLN bilinear warp; identity for alpha == 1 (mfcccpu.cpp:36-38)
+        omega = omega + 2 * std::atan((one_minus_alpha * std::sin(omega)) / (1 - one_minus_alpha * std::cos(omega)));
+        centre[i] = sample_rate * omega / (2 * kPiF);
+        out.beg[i] = round_bin(centre[i], fft_size, sample_rate);
+    }
+    for (int m = 0; m < num_banks; ++m) {
+        const float left = centre[m], mid = centre[m + 1], right = centre[m + 2];
+        const int first = round_bin(left, fft_size, sample_rate);
+        const int last = round_bin(right, fft_size, sample_rate);
+        float *row = out.weights.data() + (size_t)(m & 1) * fft_size;
+        for (int bin = first; bin < last; ++bin) {
+            if (bin < 0 || bin >= fft_size) continue;
+            float hz = bin * sample_rate / (fft_size);
+            float rising = (hz - left) / (mid - left);
+            float falling = (hz - right) / (mid - right);
+            row[bin] = std::max(0.0f, std::min(rising, falling));
+        }
+    }
+}
+
+void build_dct_matrix(int num_banks, int ceps_len, bool want_c0, float lift_coef, std::vector<float> &out)
+{
+    const int dct_len = ceps_len + (want_c0 ? 1 : 0);
+    out.assign((size_t)num_banks * dct_len, 0.0f);
+    const float norm = (float)std::sqrt(2.0 / num_banks);
+    for (int bank = 0; bank < num_banks; ++bank) {
+        float *row = out.data() + (size_t)bank * dct_len;
+        for (int c = 1; c <= ceps_len; ++c) {
+            float lifter = (1 + lift_coef / 2 * sinf(kPiF * (float)c / lift_coef));
+            row[c - 1] = lifter * norm * cosf(kPiF * c * (bank + 0.5f) / num_banks);
+        }
+        if (want_c0) row[ceps_len] = norm;
+    }
+}
+
+void build_twiddles(int n, int count, std::vector<float> &t)
+{
+    t.resize((size_t)2 * count);
+    for (int k = 0; k < count; ++k) {
+        double ang = -2.0 * 3.14159265358979323846264338 * (double)k / (double)n;
+        t[2 * k] = (float)std::cos(ang);
+        t[2 * k + 1] = (float)std::sin(ang);
+    }
+}
+
+} // namespace mfx

@@ -1,0 +1,286 @@
+"""ctypes bindings for libmfcchip.so and the Python mirror of the reference's parameterizer API.
+
+``MfccHip`` keeps the method names, argument meaning and error behaviour of the reference's
+``ParamBase`` / ``MfccBase`` interface (parambase.h:6-33, mfccbase.h:21-35) that ``MfccCpu`` and
+``MfccOpenCL`` implement: ``set_window, set_input, flush, set_alpha, apply,
+get_output_data_width, get_output_data, get_input_buffer_size, estimated_window_count``.
+Errors the reference throws as ``std::runtime_error`` surface as ``MfxError`` with the same text.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+NORM_NONE, NORM_CMN, NORM_CVN, NORM_MINMAX = 0, 1, 2, 3   # normalizer.h:5
+DYN_NONE, DYN_DELTA, DYN_ACC = 0, 1, 2                     # parambase.h:9
+
+
+class MfxError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+class MfxConfig(C.Structure):
+    """POD mirror of ``mfx_config`` (include/mfx.h)."""
+    _fields_ = [
+        ("input_buffer_size", C.c_int32),
+        ("window_size", C.c_int32),
+        ("shift", C.c_int32),
+        ("num_banks", C.c_int32),
+        ("sample_rate", C.c_float),
+        ("low_freq", C.c_float),
+        ("high_freq", C.c_float),
+        ("ceps_len", C.c_int32),
+        ("want_c0", C.c_int32),
+        ("lift_coef", C.c_float),
+        ("norm", C.c_int32),
+        ("dyn", C.c_int32),
+        ("delta_l1", C.c_int32),
+        ("delta_l2", C.c_int32),
+        ("norm_after_dyn", C.c_int32),
+        ("fft_size", C.c_int32),
+        ("channels", C.c_int32),
+        ("bug_compat", C.c_int32),
+        ("reserved", C.c_int32 * 5),
+    ]
+
+
+# every symbol include/mfx.h declares
+EXPORTED_SYMBOLS = (
+    "mfx_create", "mfx_destroy", "mfx_last_error", "mfx_status_string", "mfx_abi_version",
+    "mfx_set_window", "mfx_set_input", "mfx_flush", "mfx_set_alpha", "mfx_apply",
+    "mfx_get_output_data_width", "mfx_get_output_data", "mfx_get_input_buffer_size",
+    "mfx_estimated_window_count", "mfx_max_frames_out", "mfx_fft_size",
+    "mfx_batch_frames", "mfx_batch_plan", "mfx_batch_run_device", "mfx_batch_run_host",
+    "mfx_set_stream", "mfx_synchronize", "mfx_profile_enable", "mfx_profile_read",
+    "mfx_dominant_kernel_name", "mfx_debug_read",
+)
+
+
+def library_path():
+    return os.path.join(_HERE, "libmfcchip.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Load libmfcchip.so and declare the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = library_path()
+    if not os.path.exists(p):
+        raise MfxError(-6, "libmfcchip.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(p)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    fp, sp = C.POINTER(C.c_float), C.POINTER(C.c_int16)
+    L.mfx_create.argtypes = [C.POINTER(MfxConfig), C.c_int, C.POINTER(vp)]
+    L.mfx_destroy.argtypes = [vp]
+    L.mfx_destroy.restype = None
+    L.mfx_last_error.argtypes, L.mfx_last_error.restype = [vp], C.c_char_p
+    L.mfx_status_string.argtypes, L.mfx_status_string.restype = [C.c_int], C.c_char_p
+    L.mfx_abi_version.argtypes = []
+    L.mfx_set_window.argtypes = [vp, fp]
+    L.mfx_set_input.argtypes = [vp, sp, i32, C.POINTER(i32)]
+    L.mfx_flush.argtypes = [vp, C.POINTER(i32)]
+    L.mfx_set_alpha.argtypes = [vp, C.c_float]
+    L.mfx_apply.argtypes = [vp]
+    L.mfx_get_output_data_width.argtypes = [vp]
+    L.mfx_get_output_data.argtypes = [vp, fp, i32]
+    L.mfx_get_input_buffer_size.argtypes = [vp]
+    L.mfx_estimated_window_count.argtypes = [vp, i32]
+    L.mfx_max_frames_out.argtypes = [vp]
+    L.mfx_fft_size.argtypes = [vp]
+    L.mfx_batch_frames.argtypes, L.mfx_batch_frames.restype = [vp, i64], i64
+    L.mfx_batch_plan.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+    L.mfx_batch_run_device.argtypes = [vp, vp, i64, vp]
+    L.mfx_batch_run_host.argtypes = [vp, sp, i64, fp]
+    L.mfx_set_stream.argtypes = [vp, vp]
+    L.mfx_synchronize.argtypes = [vp]
+    L.mfx_profile_enable.argtypes = [vp, C.c_int]
+    L.mfx_profile_read.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_double), C.c_int]
+    L.mfx_dominant_kernel_name.argtypes, L.mfx_dominant_kernel_name.restype = [vp], C.c_char_p
+    L.mfx_debug_read.argtypes, L.mfx_debug_read.restype = [vp, C.c_int, vp, i64], i64
+    _lib = L
+    return L
+
+
+def reference_window(window_size):
+    """The window the reference's caller builds (ASR_OCL.cpp:149-151):
+    ``(float)(0.56f - 0.46f*cos((2.0f*M_PI*i)/W)) / 32768.f`` -- note 0.56 and a denominator of W."""
+    i = np.arange(window_size, dtype=np.float64)
+    inner = np.float32(0.56) - np.float32(0.46) * np.cos((2.0 * np.pi * i) / window_size)
+    return (inner.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+
+
+class MfccHip:
+    """Python mirror of ``class MfccHip : public MfccBase`` (host/afet_param.h).
+
+    Constructor arguments are those of MfccBase (mfccbase.h:21-35) in the same order; ``device``
+    replaces MfccOpenCL's trailing ``cl_device_id`` (mfccopencl.h:60).
+    """
+
+    def __init__(self, input_buffer_size, window_size, shift, num_banks, sample_rate, low_freq, high_freq,
+                 ceps_len, want_c0, lift_coef, norm=NORM_NONE, dyn=DYN_NONE, delta_l1=1, delta_l2=1,
+                 norm_after_dyn=True, device=0, fft_size=0, channels=1, bug_compat=True):
+        self._L = load_library()
+        self.cfg = MfxConfig(int(input_buffer_size), int(window_size), int(shift), int(num_banks),
+                             float(sample_rate), float(low_freq), float(high_freq), int(ceps_len),
+                             int(bool(want_c0)), float(lift_coef), int(norm), int(dyn), int(delta_l1),
+                             int(delta_l2), int(bool(norm_after_dyn)), int(fft_size), int(channels),
+                             int(bool(bug_compat)))
+        h = C.c_void_p()
+        rc = self._L.mfx_create(C.byref(self.cfg), int(device), C.byref(h))
+        if rc != 0:
+            raise MfxError(rc, "mfx_create: " + self._L.mfx_status_string(rc).decode())
+        self._h = h
+        self._plan_rows = None
+        self._plan_total = 0
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mfx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MfxError(rc, self._L.mfx_last_error(self._h).decode() or self._L.mfx_status_string(rc).decode())
+
+    # -- ParamBase interface (parambase.h:23-32) ----------------------------------------------------
+    def get_input_buffer_size(self):
+        return self._L.mfx_get_input_buffer_size(self._h)
+
+    def estimated_window_count(self, samples):
+        return self._L.mfx_estimated_window_count(self._h, int(samples))
+
+    def set_alpha(self, alpha):
+        self._chk(self._L.mfx_set_alpha(self._h, float(alpha)))
+
+    def set_window(self, window):
+        w = np.ascontiguousarray(window, dtype=np.float32)
+        if w.size != self.cfg.window_size:
+            raise ValueError("window must have window_size taps")
+        self._chk(self._L.mfx_set_window(self._h, w.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def set_input(self, data):
+        pcm = np.ascontiguousarray(data, dtype=np.int16)
+        n = C.c_int32(0)
+        self._chk(self._L.mfx_set_input(self._h, pcm.ctypes.data_as(C.POINTER(C.c_int16)), pcm.size, C.byref(n)))
+        return n.value
+
+    def flush(self):
+        n = C.c_int32(0)
+        self._chk(self._L.mfx_flush(self._h, C.byref(n)))
+        return n.value
+
+    def apply(self):
+        self._chk(self._L.mfx_apply(self._h))
+
+    def get_output_data_width(self):
+        return self._L.mfx_get_output_data_width(self._h)
+
+    def get_output_data(self, window_count):
+        out = np.empty((max(int(window_count), 0), self.get_output_data_width()), dtype=np.float32)
+        self._chk(self._L.mfx_get_output_data(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), int(window_count)))
+        return out
+
+    # -- extensions ---------------------------------------------------------------------------------
+    def max_frames_out(self):
+        return self._L.mfx_max_frames_out(self._h)
+
+    def fft_size(self):
+        return self._L.mfx_fft_size(self._h)
+
+    def process_stream(self, pcm, block_samples=0, alpha=1.0):
+        """The per-file loop of the reference driver (ASR_OCL.cpp:227-301): blocks of at most
+        get_input_buffer_size() samples through set_input/apply/get_output_data, then flush."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        limit = self.get_input_buffer_size()
+        if block_samples and block_samples < limit:
+            limit = int(block_samples)
+        rows, pos = [], 0
+        while pos < pcm.size:
+            n = self.set_input(pcm[pos:pos + limit])
+            self.set_alpha(alpha)
+            self.apply()
+            rows.append(self.get_output_data(n))
+            pos += limit
+        n = self.flush()
+        if n > 0:
+            self.set_alpha(alpha)
+            self.apply()
+            rows.append(self.get_output_data(n))
+        return np.concatenate(rows, 0) if rows else np.zeros((0, self.get_output_data_width()), np.float32)
+
+    # -- batch interface ----------------------------------------------------------------------------
+    def batch_frames(self, samples):
+        return int(self._L.mfx_batch_frames(self._h, int(samples)))
+
+    def batch_plan(self, offsets, lengths):
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        ln = np.ascontiguousarray(lengths, dtype=np.int64)
+        assert off.size == ln.size
+        rows = np.zeros(off.size, dtype=np.int64)
+        total = C.c_int64(0)
+        p64 = C.POINTER(C.c_int64)
+        self._chk(self._L.mfx_batch_plan(self._h, off.size, off.ctypes.data_as(p64), ln.ctypes.data_as(p64),
+                                         rows.ctypes.data_as(p64), C.byref(total)))
+        self._plan_rows, self._plan_total = rows, total.value
+        return rows, total.value
+
+    def batch_run_device(self, d_pcm_ptr, pcm_samples_total, d_out_ptr):
+        """Device pointers in, device pointer out; asynchronous on the handle's stream."""
+        self._chk(self._L.mfx_batch_run_device(self._h, C.c_void_p(int(d_pcm_ptr)), int(pcm_samples_total),
+                                               C.c_void_p(int(d_out_ptr))))
+
+    def batch_run_host(self, pcm):
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        total = pcm.size // max(self.cfg.channels, 1)
+        out = np.zeros((self._plan_total, self.get_output_data_width()), dtype=np.float32)
+        self._chk(self._L.mfx_batch_run_host(self._h, pcm.ctypes.data_as(C.POINTER(C.c_int16)), total,
+                                             out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def set_stream(self, hip_stream_handle):
+        self._chk(self._L.mfx_set_stream(self._h, C.c_void_p(int(hip_stream_handle))))
+
+    def synchronize(self):
+        self._chk(self._L.mfx_synchronize(self._h))
+
+    def profile_enable(self, on=True):
+        self._chk(self._L.mfx_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self, reset=True):
+        n, ms = C.c_int32(0), C.c_double(0)
+        self._chk(self._L.mfx_profile_read(self._h, C.byref(n), C.byref(ms), int(bool(reset))))
+        return n.value, ms.value
+
+    def dominant_kernel_name(self):
+        return self._L.mfx_dominant_kernel_name(self._h).decode()
+
+    def debug_read(self, kind):
+        W2, nb = self.fft_size(), self.cfg.num_banks
+        dl = self.cfg.ceps_len + (1 if self.cfg.want_c0 else 0)
+        if kind == 1:
+            buf = np.zeros(nb + 2, dtype=np.int32)
+        elif kind == 0:
+            buf = np.zeros(2 * W2, dtype=np.float32)
+        elif kind == 2:
+            buf = np.zeros(max(nb * dl, 1), dtype=np.float32)
+        else:
+            buf = np.zeros(64 * 1024 * 1024 // 4, dtype=np.float32)
+        n = self._L.mfx_debug_read(self._h, int(kind), buf.ctypes.data_as(C.c_void_p), buf.nbytes)
+        if n < 0:
+            raise MfxError(int(n), "mfx_debug_read failed")
+        return buf[:n].copy()
