@@ -9,6 +9,7 @@ constructors raise.  (The directory name is not an importable identifier; load i
 ``importlib`` as ``__graft_entry__.load_package()`` does, or put the parent directory on
 ``sys.path`` and use ``importlib.import_module("asr-featext-opencl_amd")``.)
 """
+from . import mfcc  # noqa: F401
 from .mfcc import (  # noqa: F401
     DYN_ACC,
     DYN_DELTA,
@@ -20,6 +21,9 @@ from .mfcc import (  # noqa: F401
     MfccHip,
     MfxConfig,
     MfxError,
+    host_dct_matrix,
+    host_frame_count,
+    host_mel_table,
     library_path,
     load_library,
     reference_window,

@@ -59,7 +59,7 @@ struct mfx_handle {
     // derived (mfccbase.cpp:18-30, mfcccpu.cpp:94-105)
     int W = 0, S = 0, W2 = 0, nb = 0, ceps = 0, dl = 0, cols = 0, width = 0;
     int l1 = 0, l2 = 0, D = 0;
-    int input_window_limit = 0, input_buffer_size = 0, window_limit = 0;
+    int input_window_limit = 0, input_buffer_size = 0, window_limit = 0, cap_rows = 0;
     int spec_pitch = 0;
     int channels = 1;
     bool fast512 = false;
@@ -393,20 +393,24 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
     if (rc != MFX_OK) return bail(rc);
 
     // ---- streaming buffers (capacity as the reference: segmentercpu.cpp:40-41, mfcccpu.cpp:104-112)
-    h->carry_capacity = (size_t)h->window_limit * h->S + h->W - h->S;
+    // The reference sizes these from window_limit alone (segmentercpu.cpp:40-41, mfcccpu.cpp:104-112); a
+    // steady-state block can need up to ~W/S more frames and W more samples than that (it writes past
+    // its buffers when W - S > 2S or dyn is off), so capacity here carries that slack.
+    h->cap_rows = h->window_limit + h->W / h->S + 4;
+    h->carry_capacity = (size_t)h->cap_rows * h->S + 2 * (size_t)h->W;
     const size_t carry_alloc = (h->carry_capacity + h->W2 + 8) & ~(size_t)1;
     for (int i = 0; i < 2; ++i) {
         if (h->d_carry[i].alloc(carry_alloc) != hipSuccess) return bail(MFX_ERR_DEVICE);
         if (hipMemset(h->d_carry[i].p, 0, carry_alloc * sizeof(int16_t)) != hipSuccess) return bail(MFX_ERR_DEVICE);
     }
-    if (h->d_spec.alloc((size_t)h->window_limit * h->spec_pitch) != hipSuccess) return bail(MFX_ERR_DEVICE);
-    if (h->d_src.alloc((size_t)h->window_limit * h->cols) != hipSuccess) return bail(MFX_ERR_DEVICE);
-    if (h->d_blk.alloc((size_t)h->window_limit * h->width) != hipSuccess) return bail(MFX_ERR_DEVICE);
+    if (h->d_spec.alloc((size_t)h->cap_rows * h->spec_pitch) != hipSuccess) return bail(MFX_ERR_DEVICE);
+    if (h->d_src.alloc((size_t)h->cap_rows * h->cols) != hipSuccess) return bail(MFX_ERR_DEVICE);
+    if (h->d_blk.alloc((size_t)h->cap_rows * h->width) != hipSuccess) return bail(MFX_ERR_DEVICE);
     if (h->d_stats_stream.alloc((size_t)3 * 2 * h->cols) != hipSuccess) return bail(MFX_ERR_DEVICE);
     if (hipMemset(h->d_stats_stream.p, 0, (size_t)3 * 2 * h->cols * sizeof(float)) != hipSuccess)
         return bail(MFX_ERR_DEVICE);
     {
-        h->n_chunks_stream_max = (h->window_limit + kChunkFrames - 1) / kChunkFrames;
+        h->n_chunks_stream_max = (h->cap_rows + kChunkFrames - 1) / kChunkFrames;
         std::vector<Chunk> ch(h->n_chunks_stream_max);
         for (int i = 0; i < h->n_chunks_stream_max; ++i) {
             ch[i].pcm_off = (int64_t)i * kChunkFrames * h->S;
@@ -434,7 +438,7 @@ extern "C" int mfx_estimated_window_count(const mfx_handle *h, int32_t samples)
 {
     return h ? estimated_window_count_f32(samples, h->W, h->S) : MFX_ERR_ARG;
 }
-extern "C" int mfx_max_frames_out(const mfx_handle *h) { return h ? h->input_window_limit + 2 : MFX_ERR_ARG; }
+extern "C" int mfx_max_frames_out(const mfx_handle *h) { return h ? h->input_window_limit + h->W / h->S + 3 : MFX_ERR_ARG; }
 extern "C" int mfx_fft_size(const mfx_handle *h) { return h ? h->W2 : MFX_ERR_ARG; }
 
 extern "C" int mfx_set_alpha(mfx_handle *h, float alpha)
@@ -653,7 +657,7 @@ extern "C" int mfx_apply(mfx_handle *h)
         wc = wcnd - 2 * D;
         if (wc <= 0) return MFX_OK;
     }
-    if (wcnd > h->window_limit) return fail(h, MFX_ERR_WINDOW_HIGH, kMsgHigh);
+    if (wcnd > h->cap_rows) return fail(h, MFX_ERR_WINDOW_HIGH, kMsgHigh);
 
     int rc = refresh_mel(h);
     if (rc != MFX_OK) return rc;
@@ -742,7 +746,7 @@ extern "C" int mfx_apply(mfx_handle *h)
 extern "C" int mfx_get_output_data(mfx_handle *h, float *data_out, int32_t frames)
 {
     if (!h || (!data_out && frames > 0) || frames < 0) return MFX_ERR_ARG;
-    if (frames > h->window_limit) return fail(h, MFX_ERR_WINDOW_HIGH, kMsgHigh);
+    if (frames > h->cap_rows) return fail(h, MFX_ERR_WINDOW_HIGH, kMsgHigh);
     if (frames == 0) return MFX_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(data_out, h->d_blk.p, sizeof(float) * (size_t)frames * h->width, hipMemcpyDeviceToHost,
@@ -983,4 +987,35 @@ extern "C" int64_t mfx_debug_read(mfx_handle *h, int kind, void *dst, int64_t ds
     if (hipStreamSynchronize(h->stream) != hipSuccess) return MFX_ERR_DEVICE;
     if (hipMemcpy(dst, src, (size_t)(count * esz), hipMemcpyDeviceToHost) != hipSuccess) return MFX_ERR_DEVICE;
     return count;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side table builders (no device)
+// ------------------------------------------------------------------------------------------------
+
+extern "C" int mfx_host_mel_table(int32_t num_banks, int32_t fft_size, float sample_rate, float low_freq,
+                                  float high_freq, float alpha, float *weights, int32_t *beg)
+{
+    if (num_banks <= 0 || fft_size <= 0 || !weights || !beg) return MFX_ERR_ARG;
+    MelTable t;
+    build_mel_table(num_banks, fft_size, sample_rate, low_freq, high_freq, alpha, t);
+    std::memcpy(weights, t.weights.data(), sizeof(float) * t.weights.size());
+    std::memcpy(beg, t.beg.data(), sizeof(int32_t) * t.beg.size());
+    return MFX_OK;
+}
+
+extern "C" int mfx_host_dct_matrix(int32_t num_banks, int32_t ceps_len, int32_t want_c0, float lift_coef,
+                                   float *matrix)
+{
+    if (num_banks <= 0 || ceps_len <= 0 || !matrix) return MFX_ERR_ARG;
+    std::vector<float> m;
+    build_dct_matrix(num_banks, ceps_len, want_c0 != 0, lift_coef, m);
+    std::memcpy(matrix, m.data(), sizeof(float) * m.size());
+    return MFX_OK;
+}
+
+extern "C" int64_t mfx_host_frame_count(int64_t samples, int32_t window_size, int32_t shift)
+{
+    if (window_size <= 0 || shift <= 0) return MFX_ERR_ARG;
+    return frame_count(samples, window_size, shift);
 }

@@ -57,6 +57,7 @@ EXPORTED_SYMBOLS = (
     "mfx_batch_frames", "mfx_batch_plan", "mfx_batch_run_device", "mfx_batch_run_host",
     "mfx_set_stream", "mfx_synchronize", "mfx_profile_enable", "mfx_profile_read",
     "mfx_dominant_kernel_name", "mfx_debug_read",
+    "mfx_host_mel_table", "mfx_host_dct_matrix", "mfx_host_frame_count",
 )
 
 
@@ -75,6 +76,14 @@ def load_library():
     p = library_path()
     if not os.path.exists(p):
         raise MfxError(-6, "libmfcchip.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+    # PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  A process must hold ONE HIP
+    # runtime: if torch is going to be used alongside (device tensors, torch.distributed), it has to be
+    # loaded first so that libmfcchip.so binds to the runtime already in the process instead of
+    # bringing /opt/rocm's in as a second one ("no ROCm-capable device" on whichever comes second).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(p)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     fp, sp = C.POINTER(C.c_float), C.POINTER(C.c_int16)
@@ -105,8 +114,37 @@ def load_library():
     L.mfx_profile_read.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_double), C.c_int]
     L.mfx_dominant_kernel_name.argtypes, L.mfx_dominant_kernel_name.restype = [vp], C.c_char_p
     L.mfx_debug_read.argtypes, L.mfx_debug_read.restype = [vp, C.c_int, vp, i64], i64
+    L.mfx_host_mel_table.argtypes = [i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, fp, C.POINTER(i32)]
+    L.mfx_host_dct_matrix.argtypes = [i32, i32, i32, C.c_float, fp]
+    L.mfx_host_frame_count.argtypes, L.mfx_host_frame_count.restype = [i64, i32, i32], i64
     _lib = L
     return L
+
+
+def host_mel_table(num_banks, fft_size, sample_rate, low_freq, high_freq, alpha=1.0):
+    """Mel table exactly as uploaded to the device (host code, no GPU needed)."""
+    L = load_library()
+    w = np.zeros((2, fft_size), dtype=np.float32)
+    beg = np.zeros(num_banks + 2, dtype=np.int32)
+    rc = L.mfx_host_mel_table(num_banks, fft_size, sample_rate, low_freq, high_freq, alpha,
+                              w.ctypes.data_as(C.POINTER(C.c_float)), beg.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc != 0:
+        raise MfxError(rc, "mfx_host_mel_table failed")
+    return w, beg
+
+
+def host_dct_matrix(num_banks, ceps_len, want_c0, lift_coef):
+    L = load_library()
+    m = np.zeros((num_banks, ceps_len + (1 if want_c0 else 0)), dtype=np.float32)
+    rc = L.mfx_host_dct_matrix(num_banks, ceps_len, int(bool(want_c0)), lift_coef,
+                               m.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc != 0:
+        raise MfxError(rc, "mfx_host_dct_matrix failed")
+    return m
+
+
+def host_frame_count(samples, window_size, shift):
+    return int(load_library().mfx_host_frame_count(int(samples), int(window_size), int(shift)))
 
 
 def reference_window(window_size):

@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MFCC hot path on MI355X.
+
+Metric (BASELINE.json): audio frames/sec at 16 kHz, 25 ms / 10 ms, 512-pt FFT, 40 mel, 13 MFCC
++ delta + delta-delta.  Workload at every N: BASELINE configs[1] per GPU -- 1000 synthetic 10 s
+utterances (998 000 frames) resident in HBM; one "step" = one pass of the whole hot path
+(int16 PCM -> [frames][39] float features) over that batch, outputs left in HBM.  Ranks own
+independent utterance shards (weak scaling, no data-path collective; torch.distributed is used
+only for the barrier and the max-over-ranks of the timing).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as G  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+FP32_PEAK_TFLOPS = 157.3
+
+WORKLOADS = {
+    # name: (n_utt, utt_samples, sample_rate, W, S, fft, nb, nc, dyn)
+    "C2": dict(n_utt=1000, utt_samples=160000, sr=16000.0, W=400, S=160, fft=0, nb=40, nc=13, dyn=2,
+               desc="1000 synthetic 16 kHz utterances x 10 s, 25 ms/10 ms, 512-pt FFT, 40 mel, 13 MFCC + d + dd"),
+    "C3": dict(n_utt=1, utt_samples=57600000, sr=16000.0, W=400, S=160, fft=1024, nb=80, nc=13, dyn=0,
+               desc="one 1-hour 16 kHz stream, 1024-pt FFT, 80 mel, 13 MFCC"),
+    "C5": dict(n_utt=200, utt_samples=441000, sr=44100.0, W=1102, S=441, fft=0, nb=128, nc=40, dyn=2,
+               desc="200 synthetic 44.1 kHz utterances x 10 s, 2048-pt FFT, 128 mel, 40 MFCC + d + dd (mono)"),
+}
+
+
+def synth_pcm_torch(torch, n_utt, utt_samples, sr, seed, device):
+    """int16 PCM [n_utt, utt_samples]: clip16(round(3000*N(0,1) + 6000*sin(2*pi*f_u*n/sr))),
+    f_u = 100 + 37*(u mod 64) Hz.  Generated on the device, in slabs."""
+    g = torch.Generator(device=device)
+    g.manual_seed(0x5EED0000 + seed)
+    pcm = torch.empty((n_utt, utt_samples), dtype=torch.int16, device=device)
+    n = torch.arange(utt_samples, device=device, dtype=torch.float32)
+    slab = max(1, min(n_utt, (1 << 26) // max(utt_samples, 1)))
+    for u0 in range(0, n_utt, slab):
+        u1 = min(n_utt, u0 + slab)
+        f = 100.0 + 37.0 * (torch.arange(u0, u1, device=device) % 64).to(torch.float32)
+        x = 3000.0 * torch.randn((u1 - u0, utt_samples), generator=g, device=device, dtype=torch.float32)
+        x += 6000.0 * torch.sin((2.0 * np.pi / sr) * f[:, None] * n[None, :])
+        pcm[u0:u1] = torch.clamp(torch.round(x), -32768, 32767).to(torch.int16)
+        del x
+    return pcm
+
+
+def cpu_baseline(orc, wl, pcm_host, window, budget_s=12.0):
+    """Oracle (kind "port") timed on this host's cores over a bounded sample of the same workload."""
+    import ctypes
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # a -march=native build of the same source if the compiler is here; else the portable one
+    libpath = None
+    try:
+        import subprocess
+        import tempfile
+        d = tempfile.mkdtemp(prefix="orc_native_")
+        out = os.path.join(d, "liboracle_native.so")
+        r = subprocess.run(["gcc", "-std=c99", "-O3", "-march=native", "-fPIC", "-fopenmp", "-shared", "-o", out,
+                            os.path.join(ROOT, "oracle", "mfcc_oracle.c"), "-lm"],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode == 0:
+            libpath = out
+    except Exception:
+        libpath = None
+    cfg = orc.make_config(wl["utt_samples"] + 1000, window_size=wl["W"], shift=wl["S"], num_banks=wl["nb"],
+                          sample_rate=wl["sr"], high_freq=wl["sr"] / 2, ceps_len=wl["nc"], dyn=wl["dyn"],
+                          delta_l1=3, delta_l2=3, fft_mode=1)
+    n_avail = pcm_host.shape[0]
+
+    def run(n_utt, threads, reps):
+        frames, sec = orc.bench_batch(cfg, pcm_host[:n_utt], window, n_threads=threads, reps=reps, libpath=libpath)
+        return frames / sec, sec, frames
+
+    # single thread first (the reference itself is single-threaded: ASR_OCL.cpp:365-366)
+    r1, _, _ = run(min(n_avail, 2), 1, 1)
+    fpu = wl_frames(wl) // wl["n_utt"]
+    n1 = int(max(1, min(n_avail, (budget_s * 0.25) * r1 / fpu)))
+    r1, dt1, f1 = run(n1, 1, 1)
+    # all host threads: repeat the resident sample until ~budget seconds of work
+    n_all = n_avail
+    est = r1 * cores * 0.5
+    reps = int(max(1, (budget_s * 0.75) * est / (fpu * n_all)))
+    rall, dtall, fall = run(n_all, cores, reps)
+    return {
+        "value": rall, "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": "%d utterances of the workload x %d passes = %d frames on all %d host threads (OpenMP, one "
+                  "extractor per thread, setup untimed), %.1f s; oracle/mfcc_oracle.c with its float32 FFT, %s build"
+                  % (n_all, reps, fall, cores, dtall, "-march=native" if libpath else "portable -mavx2"),
+        "single_thread_value": r1, "single_thread_sample": "%d utterances, %.1f s" % (n1, dt1),
+    }
+
+
+def wl_frames(wl):
+    per = (wl["utt_samples"] - (wl["W"] - wl["S"])) // wl["S"]
+    return per * wl["n_utt"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    pkg = G.load_package()
+    wl = WORKLOADS[args.workload]
+    W, S = wl["W"], wl["S"]
+    window = pkg.reference_window(W)
+
+    # ---- synthetic input resident in HBM (per rank: its own shard of utterances)
+    pcm = synth_pcm_torch(torch, wl["n_utt"], wl["utt_samples"], wl["sr"], seed=rank, device=device)
+    m = pkg.MfccHip(wl["utt_samples"] + 1000, W, S, wl["nb"], wl["sr"], 64.0, wl["sr"] / 2, wl["nc"], False, 22.0,
+                    pkg.NORM_NONE, wl["dyn"], 3, 3, True, device=local_rank, fft_size=wl["fft"])
+    m.set_window(window)
+    offsets = np.arange(wl["n_utt"], dtype=np.int64) * wl["utt_samples"]
+    lengths = np.full(wl["n_utt"], wl["utt_samples"], dtype=np.int64)
+    rows, total_rows = m.batch_plan(offsets, lengths)
+    width = m.get_output_data_width()
+    out = torch.empty((total_rows, width), dtype=torch.float32, device=device)
+    n_samples = pcm.numel()
+    torch.cuda.synchronize()
+
+    def step():
+        m.batch_run_device(pcm.data_ptr(), n_samples, out.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    m.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    m.profile_enable(True)
+    m.profile_read(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    m.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    launches, kernel_ms = m.profile_read(reset=True)
+    m.profile_enable(False)
+
+    frames_rank = int(total_rows)
+    frames_all = frames_rank * world
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = frames_all / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel (HIP events on the handle's stream around that kernel)
+    bytes_in = 2 * S
+    cols = wl["nc"] if wl["nc"] > 0 else wl["nb"]
+    kname = m.dominant_kernel_name()
+    # the front-end kernel reads each PCM sample once and writes the static coefficients once;
+    # the (small) delta kernel adds the remaining 4*2*cols B/frame of output
+    kernel_bytes_per_frame = bytes_in + 4 * cols
+    path_bytes_per_frame = bytes_in + 4 * width
+    avg_kernel_ms = kernel_ms / max(launches, 1)
+    launches_per_step = max(launches, 1) / args.steps
+    achieved = (kernel_bytes_per_frame * frames_rank / launches_per_step) / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("workload") == args.workload and tj.get("kernel") == kname:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "kernel": kname, "kernel_avg_ms": avg_kernel_ms, "kernel_launches_per_step": launches_per_step,
+        "algorithmic_bytes_per_frame": kernel_bytes_per_frame,
+        "whole_path": {"bytes_per_frame": path_bytes_per_frame,
+                       "achieved": path_bytes_per_frame * frames_rank / (ms_per_step * 1e-3) / 1e9,
+                       "frac": path_bytes_per_frame * frames_rank / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+    }
+
+    result = {
+        "metric": "audio frames/sec (16 kHz, 25 ms/10 ms, 512-pt FFT, 40 mel, 13 MFCC + delta + delta-delta)"
+                  if args.workload == "C2" else "audio frames/sec (%s)" % wl["desc"],
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %s; per GPU, resident in HBM" % (args.workload, wl["desc"]),
+                   "frames_per_gpu_per_step": frames_rank, "utterances_per_gpu": wl["n_utt"],
+                   "sharding": "independent utterance shards per rank, no collective"},
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        orc = G.load_oracle()
+        n_host = min(wl["n_utt"], 512)
+        pcm_host = pcm[:n_host].cpu().numpy()
+        result["cpu_baseline"] = cpu_baseline(orc, wl, pcm_host, window)
+        result["cpu_baseline"]["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+    m.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

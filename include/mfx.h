@@ -152,6 +152,16 @@ int mfx_profile_read(mfx_handle *h, int32_t *launches, double *kernel_ms, int re
 /* name of the dominant kernel as it appears in rocprofv3's kernel trace */
 const char *mfx_dominant_kernel_name(const mfx_handle *h);
 
+/* ---- host-side table builders (no device needed; the same code fills the tables the kernels
+ *      read, exposed so that CPU-only tests can compare them with the oracle bit for bit) ---- */
+/* mel table of MfccCpu::refresh_filters (mfcccpu.cpp:24-60): weights [2][fft_size], beg [num_banks+2] */
+int mfx_host_mel_table(int32_t num_banks, int32_t fft_size, float sample_rate, float low_freq, float high_freq,
+                       float alpha, float *weights, int32_t *beg);
+/* DCT-II + lifter matrix (mfcccpu.cpp:118-136): [num_banks][ceps_len + (want_c0 ? 1 : 0)] */
+int mfx_host_dct_matrix(int32_t num_banks, int32_t ceps_len, int32_t want_c0, float lift_coef, float *matrix);
+/* frame count, integer arithmetic (parambase.cpp:16-19 without the float32 division) */
+int64_t mfx_host_frame_count(int64_t samples, int32_t window_size, int32_t shift);
+
 /* ---- test taps (device -> host copies of intermediate tables; used by the parity tests) ---- */
 /* kind: 0 = mel table [2][fft_size] floats, 1 = filter_beg [num_banks+2] int32,
  *       2 = DCT matrix [num_banks][dct_len] floats, 3 = magnitude spectrum of the current block

@@ -344,7 +344,7 @@ struct orc_mfcc {
     int last_block;
     int num_banks, ceps_len, dct_len, delta_l1, delta_l2;
     /* MfccCpu members (mfcccpu.h:17-34) */
-    int buffer_size, window_limit, data_length, window_size2;
+    int buffer_size, window_limit, cap_rows, data_length, window_size2;
     float *data, *fft, *mel, *mfcc, *dct_matrix, *filters, *delta_in;
     int *filter_beg;
     /* SegmenterCPU members (segmentercpu.h:7-17) */
@@ -422,26 +422,31 @@ orc_mfcc *orc_create(const orc_config *cfg)
         free(o);
         return NULL;
     }
+    /* Capacity: the reference sizes every buffer from window_limit (mfcccpu.cpp:104-112,
+     * segmentercpu.cpp:40-41).  A steady-state block can need up to ~W/S more frames and W more
+     * samples than that (the reference then writes past its buffers: W - S > 2S, or dyn off), so the
+     * allocations here carry that slack; window_limit itself keeps the reference value. */
+    o->cap_rows = o->window_limit + o->window_size / o->shift + 4;
     o->buffer_size = o->window_limit * o->shift + o->window_size - o->shift;
-    o->data_length = o->window_limit * o->window_size2;
+    o->data_length = o->cap_rows * o->window_size2;
     /* SegmenterCPU::init, segmentercpu.cpp:30-44 */
     o->deltasize = D;
     o->remaining_samples = 0;
     o->samples = 0;
     o->flushed = 1;
     o->last_calc_flushed = 0;
-    o->tmp_capacity = (size_t)o->window_limit * o->shift + o->window_size - o->shift;
+    o->tmp_capacity = (size_t)o->cap_rows * o->shift + 2 * (size_t)o->window_size;
     o->tmpbuffer = (short *)calloc(o->tmp_capacity, sizeof(short));
     o->window = (float *)calloc(o->window_size, sizeof(float));
     /* mfcccpu.cpp:109-112 */
     o->data = (float *)calloc((size_t)o->data_length, sizeof(float));
     o->fft = (float *)calloc((size_t)o->data_length * 2, sizeof(float));
-    o->mel = (float *)calloc((size_t)o->num_banks * o->window_limit, sizeof(float));
+    o->mel = (float *)calloc((size_t)o->num_banks * o->cap_rows, sizeof(float));
     /* DCT-II + lifter matrix, mfcccpu.cpp:118-136 */
     if (o->ceps_len > 0) {
         const int nb = o->num_banks, dl = o->dct_len;
         const float lift_coef = cfg->lift_coef;
-        o->mfcc = (float *)calloc((size_t)dl * o->window_limit, sizeof(float));
+        o->mfcc = (float *)calloc((size_t)dl * o->cap_rows, sizeof(float));
         o->dct_matrix = (float *)calloc((size_t)nb * dl, sizeof(float));
         float normfact = (float)sqrt(2.0 / nb);
         for (int iy = 0; iy < nb; iy++)
@@ -462,10 +467,10 @@ orc_mfcc *orc_create(const orc_config *cfg)
     }
     /* deltas, mfcccpu.cpp:146-157 */
     if (cfg->dyn != ORC_DYN_NONE) {
-        int rows = o->window_limit + 2 * D;
-        o->delta_out = (float *)calloc((size_t)cols * (o->window_limit + 2 * o->delta_l2), sizeof(float));
+        int rows = o->cap_rows + 2 * D;
+        o->delta_out = (float *)calloc((size_t)cols * (o->cap_rows + 2 * o->delta_l2), sizeof(float));
         if (cfg->dyn == ORC_DYN_ACC)
-            o->acc_out = (float *)calloc((size_t)cols * o->window_limit, sizeof(float));
+            o->acc_out = (float *)calloc((size_t)cols * o->cap_rows, sizeof(float));
         o->delta_in = (float *)calloc((size_t)cols * rows, sizeof(float));
     }
     o->filters = (float *)calloc((size_t)2 * o->window_size2, sizeof(float));
@@ -733,7 +738,7 @@ static void get_output(float *data_out, const float *buff, int width, int height
 /* mfcccpu.cpp:427-444 */
 int orc_get_output_data(orc_mfcc *o, float *data_out, int window_count)
 {
-    if (window_count > o->window_limit) return ORC_ERR_WINDOW_HIGH;
+    if (window_count > o->cap_rows) return ORC_ERR_WINDOW_HIGH;
     const int cols = cols_of(o), pitch = orc_get_output_data_width(o);
     const float *src = o->ceps_len > 0 ? o->mfcc : o->mel;
     get_output(data_out, src + (size_t)static_offset_rows(o) * cols, cols, window_count, cols, pitch);
@@ -833,5 +838,57 @@ long long orc_run_batch(const orc_config *cfg, const float *window, const short 
         } else
             failed = 1;
     }
+    return failed ? -1 : total;
+}
+
+/* Timed variant for bench.py's cpu_baseline leg: each thread builds its extractor once, then the
+ * batch is processed `reps` times; only the processing is timed (max over threads).  Features go to
+ * a per-thread scratch row block (the point is the arithmetic, not keeping 256 copies of the
+ * output).  Returns frames processed in total, seconds through *seconds. */
+long long orc_bench_batch(const orc_config *cfg, const float *window, const short *pcm, int n_utt,
+                          int utt_samples, int n_threads, int reps, double *seconds)
+{
+    const int width = orc_output_width(cfg->num_banks, cfg->ceps_len, cfg->want_c0, cfg->dyn);
+    const int fpu = orc_ewc(utt_samples, cfg->window_size, cfg->shift);
+    long long total = 0;
+    int failed = 0;
+    double tmax = 0.0;
+    if (n_threads < 1) n_threads = 1;
+    if (fpu <= 0) return -1;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads) reduction(+ : total) reduction(max : tmax)
+#endif
+    {
+        orc_mfcc *o = orc_create(cfg);
+        float *scratch = (float *)malloc(sizeof(float) * (size_t)(fpu + 8) * width);
+        if (o && scratch) {
+            orc_set_bug_compat(o, 0);
+            orc_set_window(o, window);
+#ifdef _OPENMP
+            int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+#pragma omp barrier
+            double t0 = omp_get_wtime();
+#else
+            int tid = 0, nt = 1;
+            double t0 = 0;
+#endif
+            for (int r = 0; r < reps; r++)
+                for (int u = tid; u < n_utt; u += nt) {
+                    int n = run_stream(o, 1.0f, pcm + (size_t)u * utt_samples, utt_samples, 0, scratch);
+                    if (n < 0) {
+                        failed = 1;
+                        break;
+                    }
+                    total += n;
+                }
+#ifdef _OPENMP
+            tmax = omp_get_wtime() - t0;
+#endif
+        } else
+            failed = 1;
+        free(scratch);
+        orc_destroy(o);
+    }
+    if (seconds) *seconds = tmax;
     return failed ? -1 : total;
 }

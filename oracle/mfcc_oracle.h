@@ -119,6 +119,10 @@ int orc_run_utterance(const orc_config *cfg, const float *window, float alpha, i
 long long orc_run_batch(const orc_config *cfg, const float *window, const short *pcm, int n_utt,
                         int utt_samples, float *out, int n_threads);
 
+/* Timed variant (see mfcc_oracle.c): setup excluded, batch repeated `reps` times. */
+long long orc_bench_batch(const orc_config *cfg, const float *window, const short *pcm, int n_utt,
+                          int utt_samples, int n_threads, int reps, double *seconds);
+
 #ifdef __cplusplus
 }
 #endif

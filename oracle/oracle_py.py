@@ -115,6 +115,9 @@ def lib(path=None):
     L.orc_run_utterance.argtypes = [C.POINTER(OrcConfig), fp, C.c_float, C.c_int, sp, C.c_int, C.c_int, fp]
     L.orc_run_batch.restype = C.c_longlong
     L.orc_run_batch.argtypes = [C.POINTER(OrcConfig), fp, sp, C.c_int, C.c_int, fp, C.c_int]
+    L.orc_bench_batch.restype = C.c_longlong
+    L.orc_bench_batch.argtypes = [C.POINTER(OrcConfig), fp, sp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(C.c_double)]
     if path is None:
         _lib = L
     return L
@@ -258,6 +261,22 @@ def run_batch(cfg, pcm2d, window=None, n_threads=1, libpath=None):
     if n < 0:
         raise RuntimeError("orc_run_batch failed")
     return out.reshape(n_utt, fpu, width)
+
+
+def bench_batch(cfg, pcm2d, window=None, n_threads=1, reps=1, libpath=None):
+    """Timed CPU pass (setup excluded): returns (frames, seconds)."""
+    L = lib(libpath)
+    pcm2d = np.ascontiguousarray(pcm2d, dtype=np.int16)
+    n_utt, utt_samples = pcm2d.shape
+    if window is None:
+        window = reference_window(cfg.window_size)
+    window = np.ascontiguousarray(window, dtype=np.float32)
+    sec = C.c_double(0)
+    n = L.orc_bench_batch(C.byref(cfg), _fp(window), _sp(pcm2d), n_utt, utt_samples, int(n_threads), int(reps),
+                          C.byref(sec))
+    if n < 0:
+        raise RuntimeError("orc_bench_batch failed")
+    return int(n), float(sec.value)
 
 
 # ---------------------------------------------------------------------------------------------

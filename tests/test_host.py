@@ -1,0 +1,180 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/mfx.h
+declares, the host-built tables equal the oracle's bit for bit, the config struct mirrors the
+header, the product refuses to run without a GPU (no CPU fallback), and the N>1 sharding path
+works under torch.distributed (gloo, world_size 2)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "mfx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mfx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.load_library()
+    declared = _header_functions()
+    assert len(declared) >= 25
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, "declared in include/mfx.h but not exported: %s" % missing
+    assert set(declared) == set(pkg.mfcc.EXPORTED_SYMBOLS)
+    assert L.mfx_abi_version() == 1
+
+
+def test_config_struct_matches_header(pkg, tmp_path):
+    """sizeof/offsets of mfx_config as the C compiler sees them == the ctypes mirror."""
+    fields = [f[0] for f in pkg.MfxConfig._fields_]
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "mfx.h"', 'int main(void){',
+            'printf("%zu\\n", sizeof(mfx_config));']
+    prog += ['printf("%%zu\\n", offsetof(mfx_config, %s));' % f for f in fields]
+    prog += ['return 0;}']
+    c = tmp_path / "t.c"
+    c.write_text("\n".join(prog))
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert vals[0] == C.sizeof(pkg.MfxConfig)
+    assert vals[1:] == [getattr(pkg.MfxConfig, f).offset for f in fields]
+
+
+def test_header_is_plain_c(tmp_path):
+    c = tmp_path / "t.c"
+    c.write_text('#include "mfx.h"\nint main(void){return MFX_OK;}\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           "-c", str(c), "-o", str(tmp_path / "t.o")])
+
+
+@pytest.mark.parametrize("nb,W2,sr,low,high,alpha", [
+    (26, 512, 16000.0, 64.0, 8000.0, 1.0),
+    (40, 512, 16000.0, 64.0, 8000.0, 1.0),
+    (15, 512, 16000.0, 64.0, 8000.0, 1.0),
+    (80, 1024, 16000.0, 64.0, 8000.0, 1.0),
+    (128, 2048, 44100.0, 64.0, 22050.0, 1.0),
+    (40, 512, 16000.0, 64.0, 8000.0, 0.88),
+    (40, 512, 16000.0, 100.0, 7000.0, 1.12),
+    (23, 256, 8000.0, 64.0, 4000.0, 1.0),
+])
+def test_mel_table_equals_oracle(pkg, orc, nb, W2, sr, low, high, alpha):
+    w, beg = pkg.host_mel_table(nb, W2, sr, low, high, alpha)
+    W = W2  # any window length with ceil2(W) == W2
+    o = orc.OracleMfcc(orc.make_config(4 * W2, window_size=W, shift=W // 2, num_banks=nb, sample_rate=sr, low_freq=low,
+                                       high_freq=high, ceps_len=0, dyn=orc.DYN_NONE), np.ones(W, np.float32))
+    o.set_alpha(alpha)
+    o.set_input(np.zeros(3 * W2, np.int16))
+    o.apply()  # the oracle (like the reference) rebuilds the table inside apply()
+    t = o.tables()
+    assert np.array_equal(beg, t["filter_beg"])
+    assert np.array_equal(w, t["filters"])
+    # structural properties the kernels rely on
+    assert np.all(np.diff(beg) >= 0) and beg[0] >= 0 and beg[-1] <= W2 // 2
+    assert w.min() >= 0.0 and w.max() <= 1.0
+
+
+@pytest.mark.parametrize("nb,nc,c0,lift", [(26, 13, False, 22.0), (40, 13, False, 22.0), (15, 12, True, 22.0),
+                                           (128, 40, False, 22.0), (80, 13, True, 10.0)])
+def test_dct_matrix_equals_oracle(pkg, orc, nb, nc, c0, lift):
+    m = pkg.host_dct_matrix(nb, nc, c0, lift)
+    o = orc.OracleMfcc(orc.make_config(4000, num_banks=nb, ceps_len=nc, want_c0=c0, lift_coef=lift, dyn=orc.DYN_NONE))
+    assert np.array_equal(m, o.tables()["dct_matrix"])
+    if c0:
+        assert np.all(m[:, nc] == np.float32(np.sqrt(2.0 / nb)))  # c0 is the LAST column
+
+
+def test_frame_count_integer_vs_float32(pkg, orc):
+    L = orc.lib()
+    rng = np.random.default_rng(5)
+    for W, S in ((400, 160), (1102, 441), (1024, 160), (200, 80)):
+        for s in list(rng.integers(0, 1 << 24, size=200)) + [0, 1, W - S, W - 1, W, W + S - 1, W + S]:
+            assert pkg.host_frame_count(int(s), W, S) == L.orc_ewc(int(s), W, S)
+    # beyond 2^24 samples the reference's float32 expression is no longer exact; the product's is
+    assert pkg.host_frame_count(57600000, 400, 160) == (57600000 - 240) // 160
+
+
+def test_no_cpu_fallback(pkg):
+    """Without a GPU the product must fail loudly instead of computing on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.MfxError):
+        pkg.MfccHip(8000, 400, 160, 40, 16000.0, 64.0, 8000.0, 13, False, 22.0)
+
+
+def test_product_does_not_link_the_oracle(pkg):
+    """The shipped library must not depend on anything under oracle/."""
+    out = subprocess.check_output(["ldd", pkg.library_path()], text=True)
+    assert "oracle" not in out
+    for root, _, files in os.walk(os.path.join(ROOT, "asr-featext-opencl_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                txt = open(os.path.join(root, f), errors="ignore").read()
+                assert "oracle_py" not in txt and "mfcc_oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_sharding_round_robin(graft):
+    pkg = graft.load_package()
+    import importlib
+    sh = importlib.import_module(graft.PKG_NAME + ".sharding")
+    lengths = np.array([160000, 1001, 48000, 7, 160000, 32001, 999, 50000, 8000], dtype=np.int64)
+    seen = []
+    for r in range(4):
+        idx, off, ln, total = sh.shard_layout(lengths, r, 4)
+        assert np.array_equal(idx, np.arange(r, lengths.size, 4))
+        assert np.all(off % 2 == 0) and np.array_equal(ln, lengths[idx])
+        assert total >= ln.sum() and np.all(off[1:] >= off[:-1] + ln[:-1])
+        seen += list(idx)
+    assert sorted(seen) == list(range(lengths.size))
+    fr = sh.frames_of(lengths, 400, 160)
+    assert list(fr) == [pkg.host_frame_count(int(n), 400, 160) if n >= 400 else 0 for n in lengths]
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import __graft_entry__ as G
+import importlib
+pkg = G.load_package()
+sh = importlib.import_module(G.PKG_NAME + ".sharding")
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(7)
+lengths = rng.integers(400, 200000, size=101)
+idx, off, ln, total = sh.shard_layout(lengths, rank, world)
+local = int(sh.frames_of(ln, 400, 160).sum())
+dist.barrier()
+tot = sh.gather_counts(local, dist)
+tmax = sh.max_over_ranks(1.0 + rank, dist)
+expect = int(sh.frames_of(lengths, 400, 160).sum())
+assert tot == expect, (tot, expect)
+assert tmax == float(world), tmax
+# every utterance owned exactly once
+owned = torch.zeros(lengths.size, dtype=torch.int64); owned[torch.from_numpy(idx)] = 1
+dist.all_reduce(owned)
+assert bool((owned == 1).all())
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_rank_gloo_sharding(tmp_path):
+    """The N>1 path of bench.py / sharding.py under torch.distributed, world_size 2, gloo, CPU."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), ROOT],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert r.stdout.count("ok") >= 2
