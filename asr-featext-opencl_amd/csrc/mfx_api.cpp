@@ -70,6 +70,13 @@ struct mfx_handle {
     // tables in HBM
     DevBuf<float> d_window, d_winpair, d_twid_pass, d_twid_half, d_twid_split, d_mel_w, d_dct;
     DevBuf<int32_t> d_mel_beg;
+    // 512-point kernel: per-lane mel plan + transposed DCT matrix
+    DevBuf<float> d_mel_lane_w, d_dct_t;
+    DevBuf<int32_t> d_mel_lane_start, d_mel_lane_fid;
+    MelLanePlan plan;
+    int dct_stride = 0, nb_pad = 0;
+    bool fused_ok = false;
+    std::vector<float> h_dct;
 
     // streaming state (segmentercpu.h:7-17, parambase.h:18)
     DevBuf<int16_t> d_carry[2];
@@ -133,6 +140,8 @@ hipError_t upload(DevBuf<T> &b, const std::vector<T> &v)
     return hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
 }
 
+void fill_front(const mfx_handle *h, FrontParams &p);
+
 // rebuild the alpha-dependent mel table if needed (the reference re-derives it on every apply(),
 // mfcccpu.cpp:194; here only when alpha actually changed)
 int refresh_mel(mfx_handle *h)
@@ -146,6 +155,15 @@ int refresh_mel(mfx_handle *h)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, upload(h->d_mel_w, t.weights));
     HIP_TRY(h, upload(h->d_mel_beg, t.beg));
+    h->fused_ok = false;
+    if (h->fast512 && build_mel_lane_plan(t, h->nb, h->W2, /*max_read_bin=*/511, h->plan)) {
+        HIP_TRY(h, upload(h->d_mel_lane_w, h->plan.w));
+        HIP_TRY(h, upload(h->d_mel_lane_start, h->plan.start));
+        HIP_TRY(h, upload(h->d_mel_lane_fid, h->plan.fid));
+        FrontParams probe;
+        fill_front(h, probe);
+        h->fused_ok = front512_lds_bytes(probe) <= 160 * 1024;
+    }
     h->table_alpha = h->alpha;
     return MFX_OK;
 }
@@ -169,6 +187,15 @@ void fill_front(const mfx_handle *h, FrontParams &p)
     p.dct_len = h->dl;
     p.cols = h->cols;
     p.scale = 0.5f / (float)h->W2;
+    p.mel_lane_w = h->d_mel_lane_w.p;
+    p.mel_lane_start = h->d_mel_lane_start.p;
+    p.mel_lane_fid = h->d_mel_lane_fid.p;
+    p.dct_t = h->d_dct_t.p;
+    p.mel_rounds = h->plan.rounds;
+    p.mel_row_stride = h->plan.row_stride;
+    for (int i = 0; i < 8; ++i) p.mel_L[i] = h->plan.L[i];
+    p.dct_stride = h->dct_stride;
+    p.nb_pad = h->nb_pad > 0 ? h->nb_pad : ((h->nb + 3) & ~3);
 }
 
 struct ProfScope {
@@ -276,6 +303,10 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_mel_w.release();
     h->d_dct.release();
     h->d_mel_beg.release();
+    h->d_mel_lane_w.release();
+    h->d_dct_t.release();
+    h->d_mel_lane_start.release();
+    h->d_mel_lane_fid.release();
     h->d_carry[0].release();
     h->d_carry[1].release();
     h->d_spec.release();
@@ -387,6 +418,11 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
             std::vector<float> m;
             build_dct_matrix(h->nb, h->ceps, cfg->want_c0 != 0, cfg->lift_coef, m);
             if (upload(h->d_dct, m) != hipSuccess) return bail(MFX_ERR_DEVICE);
+            if (h->fast512) {
+                std::vector<float> mt;
+                build_dct_transposed(m, h->nb, h->dl, h->dct_stride, h->nb_pad, mt);
+                if (upload(h->d_dct_t, mt) != hipSuccess) return bail(MFX_ERR_DEVICE);
+            }
         }
     }
     rc = refresh_mel(h);
@@ -842,7 +878,7 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
     p.feat = d_out;
     p.feat_pitch = h->width;
 
-    if (h->fast512) {
+    if (h->fast512 && h->fused_ok) {
         ProfScope ps(h);
         HIP_TRY(h, launch_front512(p, /*to_spectrum=*/false, h->batch_aligned, h->nm16, h->stream));
     } else {
@@ -868,7 +904,10 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
             q.spec_pitch = h->spec_pitch;
             {
                 ProfScope ps(h);
-                HIP_TRY(h, launch_front_generic(q, h->stream));
+                if (h->fast512)
+                    HIP_TRY(h, launch_front512(q, /*to_spectrum=*/true, h->batch_aligned, h->nm16, h->stream));
+                else
+                    HIP_TRY(h, launch_front_generic(q, h->stream));
             }
             MelcepParams mp;
             std::memset(&mp, 0, sizeof(mp));

@@ -58,6 +58,14 @@ struct FrontParams {
     const float *mel_w;       // [2][W2]
     const int32_t *mel_beg;   // [nb+2]
     const float *dct;         // [nb][dct_len] or nullptr when ceps_len == 0
+    // 512 fast path: mel filters dealt to the 16 lanes of a frame in `mel_rounds` rounds, round r
+    // padded to mel_L[r] bins (multiple of 4); lane j's weights for all rounds are one row of mel_lane_w
+    const float *mel_lane_w;      // [16][mel_row_stride]
+    const int32_t *mel_lane_start;// [mel_rounds][16] first bin of the lane's filter in that round
+    const int32_t *mel_lane_fid;  // [mel_rounds][16] filter index or -1
+    const float *dct_t;           // [cols][dct_stride] transposed DCT matrix, rows zero padded to nb_pad
+    int32_t mel_rounds, mel_row_stride, dct_stride, nb_pad;
+    int32_t mel_L[8];
     int32_t num_banks;
     int32_t dct_len;
     int32_t cols;             // dct_len, or num_banks when ceps_len == 0
@@ -112,6 +120,9 @@ hipError_t launch_melcep(const MelcepParams &p, hipStream_t stream);
 hipError_t launch_delta(const DeltaParams &p, hipStream_t stream);
 hipError_t launch_norm_stats(const NormParams &p, hipStream_t stream);
 hipError_t launch_norm_apply(const NormParams &p, hipStream_t stream);
+
+// dynamic LDS bytes one block of the 512-point kernel needs for these parameters
+size_t front512_lds_bytes(const FrontParams &p);
 
 // true when the 512-point fast path can take this configuration
 bool front512_supported(int fft_size, int window_size, int num_banks, int cols, int channels);

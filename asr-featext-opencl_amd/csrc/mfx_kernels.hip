@@ -105,102 +105,152 @@ __device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// 512-point front end.  One wave owns 4 frames per iteration, 16 lanes per frame.
+// 512-point front end.  One wave owns 4 frames per iteration, 16 lanes per frame; a 512-thread
+// block is 8 such waves sharing one set of LDS tables, two blocks per CU.
 //
 //   real 512-point DFT of a frame = complex 256-point DFT of z[n] = x[2n] + i x[2n+1] + real split
 //   256 = 16 x 16:   lane l  : 16-point DFT over m of z[l + 16m]        (registers)
-//                    twiddle : * W_256^(l*k1)                            (per-lane constants)
+//                    twiddle : * W_256^(l*k1)                            (LDS table, [k1][l])
 //                    LDS     : 16x16 transpose inside the frame's lane group
 //                    lane q  : 16-point DFT over l -> Z[q + 16p], p = 0..15
 //   split:  X[k] = 1/2 * ((Z[k] + conj Z[256-k]) + (-i W_512^k)(Z[k] - conj Z[256-k]))
-//           the partner Z[256-k] lives in lane (16-q)%16 of the same 16-lane row
+//           the partner Z[256-k] lives in lane (16-q)%16 of the same 16-lane DPP row
 //   |X[k]| / 512 -> LDS (or HBM when TO_SPEC), then mel/log/DCT on the 16 lanes of the frame.
 //
-// LDS per frame slot: 16 rows x 34 dwords (row = 16 complex + 2 dwords pad: the b64 transpose
-// reads then hit 32 distinct bank pairs per half wave); the magnitudes and the mel scratch reuse
-// the same slot once the transpose has been consumed.
+// LDS per frame slot: 16 rows x 32 dwords, XOR-swizzled: (row r, column c) sits at column
+// c ^ (r & 14).  The column writes (ds_write_b64, one row per instruction) stay 128 contiguous
+// bytes; the row reads (ds_read_b128, lane q reads row q) then touch 16 distinct 16-byte bank
+// groups per 16 lanes.  Magnitudes and the mel scratch reuse the slot once the transpose is done.
+//
+// PCM is fetched with buffer loads (hardware range check: reads past the end of the array return
+// 0) one iteration ahead of its use.
 // ------------------------------------------------------------------------------------------------
-constexpr int kXRow = 34;            // dwords per transpose row
-constexpr int kXFrame = 16 * kXRow;  // 544 dwords per frame slot
-constexpr int kMelOff = 272;         // mel scratch offset inside the slot (after 257 magnitudes)
-constexpr int kBinsPad = 264;        // padded length of the LDS mel-weight rows (257 used)
+constexpr int kSlot = 512;    // dwords per frame slot
+constexpr int kMelOff = 260;  // mel scratch offset inside the slot (after 257 magnitudes)
+constexpr int kBinsPad = 264;
+
+// y[l] = x[(16 - l) & 15] inside every row of 16 lanes: mirror, then rotate right by one
+__device__ __forceinline__ float row_partner(float x)
+{
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, true); // row_mirror
+    t = __builtin_amdgcn_update_dpp(0, t, 0x121, 0xf, 0xf, true);                      // row_ror:1
+    return __int_as_float(t);
+}
+
+template <bool ALIGNED, int NM>
+struct PcmRegs {
+    uint32_t d[ALIGNED ? NM : 2 * NM];
+};
+
+// issue the loads of one iteration (4 frames); `voff` = byte offset of this lane's first pair
+template <bool ALIGNED, int NM>
+__device__ __forceinline__ void pcm_issue(PcmRegs<ALIGNED, NM> &r, __amdgpu_buffer_rsrc_t rsrc, int voff)
+{
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        if (ALIGNED) {
+            r.d[m] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + 64 * m, 0, 0);
+        } else {
+            r.d[2 * m] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + 64 * m, 0, 0);
+            r.d[2 * m + 1] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + 64 * m + 4, 0, 0);
+        }
+    }
+}
 
 template <bool ALIGNED, bool TO_SPEC, int NM>
-__global__ void __launch_bounds__(256) k_front512(FrontParams p)
+__global__ void __launch_bounds__(512, 4) k_front512(FrontParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
     const int slot = lane >> 4, l = lane & 15;
 
     // ---- LDS carve: shared tables, then one 4-slot region per wave
-    const int nb = p.num_banks, dl = p.dct_len, cols = p.cols;
-    float *s_w0 = smem;
-    float *s_w1 = s_w0 + kBinsPad;
-    float *s_split = s_w1 + kBinsPad;            // [264][2]
-    int *s_beg = (int *)(s_split + 2 * kBinsPad);
-    const int beg_pad = (nb + 2 + 3) & ~3;
-    float *s_dct = (float *)(s_beg + beg_pad);
-    const int dct_floats = (p.dct ? nb * dl : 0);
-    const int dct_pad = (dct_floats + 3) & ~3;
-    float *s_wave = s_dct + dct_pad + wave * (4 * kXFrame);
-    float *xb = s_wave + slot * kXFrame;
+    const int cols = p.cols;
+    const int rounds = p.mel_rounds, RS = p.mel_row_stride, DS = p.dct_stride, nb_pad = p.nb_pad;
+    float2 *s_win = (float2 *)smem;                  // [16 m][16 l]
+    float2 *s_tw = s_win + 256;                      // [16 k][16 l]
+    float2 *s_split = s_tw + 256;                    // [264]
+    float *s_melw = (float *)(s_split + kBinsPad);   // [16][RS]
+    int *s_mstart = (int *)(s_melw + 16 * RS);       // [rounds][16]
+    int *s_mfid = s_mstart + 16 * rounds;            // [rounds][16]
+    float *s_dct = (float *)(s_mfid + 16 * rounds);  // [cols][DS]
+    const int dct_floats = p.dct ? cols * DS : 0;
+    float *s_wave = s_dct + dct_floats + wave * (4 * kSlot);
+    float *xb = s_wave + slot * kSlot;
 
-    if (!TO_SPEC) {
-        for (int i = tid; i < 257; i += 256) {
-            s_w0[i] = p.mel_w[i];
-            s_w1[i] = p.mel_w[512 + i];
-        }
-        for (int i = tid; i < nb + 2; i += 256) s_beg[i] = p.mel_beg[i];
-        for (int i = tid; i < dct_floats; i += 256) s_dct[i] = p.dct[i];
+    for (int i = tid; i < 256; i += 512) {
+        // HBM tables are [lane][m]; the LDS copies are [m][lane] so that one row is read per instruction
+        s_win[i] = ((const float2 *)p.winpair)[(i & 15) * 16 + (i >> 4)];
+        s_tw[i] = ((const float2 *)p.twid_pass)[(i & 15) * 16 + (i >> 4)];
     }
-    for (int i = tid; i < 2 * 257; i += 256) s_split[i] = p.twid_split[i];
+    for (int i = tid; i < 257; i += 512) s_split[i] = ((const float2 *)p.twid_split)[i];
+    if (!TO_SPEC) {
+        for (int i = tid; i < 16 * RS; i += 512) s_melw[i] = p.mel_lane_w[i];
+        for (int i = tid; i < 16 * rounds; i += 512) {
+            s_mstart[i] = p.mel_lane_start[i];
+            s_mfid[i] = p.mel_lane_fid[i];
+        }
+        for (int i = tid; i < dct_floats; i += 512) s_dct[i] = p.dct_t[i];
+    }
+    // the slots are read (times zero weights) before every word has been written once: make them finite
+    for (int i = lane; i < 4 * kSlot; i += 64) s_wave[i] = 0.f;
     __syncthreads();
 
-    // ---- per-lane constants kept in registers for the whole kernel
-    float2 win[NM], tw[16];
-    {
-        const float2 *wp = (const float2 *)p.winpair + l * 16;
-#pragma unroll
-        for (int m = 0; m < NM; ++m) win[m] = wp[m];
-        const float2 *tp = (const float2 *)p.twid_pass + l * 16;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) tw[k] = tp[k];
-    }
-    const uint32_t *pcm32 = (const uint32_t *)p.pcm;
-    const int64_t max_idx = (p.pcm_total - 1) >> 1;
     const float scale = p.scale;
-    const int partner = (lane & 48) | ((16 - l) & 15);
 
-    for (int c = blockIdx.x * 4 + wave; c < p.n_chunks; c += gridDim.x * 4) {
-        const Chunk ch = p.chunks[c];
-        for (int f0 = 0; f0 < ch.n_frames; f0 += 4) {
+    for (int c = blockIdx.x * 8 + wave; c < p.n_chunks; c += gridDim.x * 8) {
+        // wave-uniform chunk descriptor -> scalar registers
+        const Chunk *chp = p.chunks + c;
+        const int64_t pcm_off = chp->pcm_off;
+        const int64_t out_row = chp->out_row;
+        const int n_frames = chp->n_frames;
+        int64_t rows_left = p.row_limit - out_row;
+        const int n_live = (int)(rows_left < n_frames ? (rows_left < 0 ? 0 : rows_left) : n_frames);
+        // buffer descriptor over [chunk start, end of PCM): out-of-range lanes read 0
+        const int64_t base_s = ALIGNED ? pcm_off : (pcm_off & ~(int64_t)1);
+        const int odd0 = ALIGNED ? 0 : (int)(pcm_off & 1);
+        int64_t bytes_left = (p.pcm_total - base_s) * 2;
+        if (bytes_left > 0xfffffff0ll) bytes_left = 0xfffffff0ll;
+        if (bytes_left < 0) bytes_left = 0;
+        const uintptr_t bp = (uintptr_t)(p.pcm + base_s);
+        const uint32_t bp_lo = __builtin_amdgcn_readfirstlane((uint32_t)bp);
+        const uint32_t bp_hi = __builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32));
+        const uint32_t nbytes = __builtin_amdgcn_readfirstlane((uint32_t)bytes_left);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(((uintptr_t)bp_hi << 32) | bp_lo), 0, nbytes, 0x00020000);
+
+        PcmRegs<ALIGNED, NM> cur, nxt;
+        // sample offset of (frame f, pair l) relative to base_s: odd0 + f*S + 2*l
+        auto lane_off = [&](int f) -> int {
+            const int s = odd0 + f * p.shift + 2 * l;  // first sample of the lane's pair
+            return ALIGNED ? s * 2 : (s & ~1) * 2;
+        };
+        pcm_issue<ALIGNED, NM>(cur, rsrc, lane_off(slot));
+
+        for (int f0 = 0; f0 < n_live; f0 += 4) {
             const int f = f0 + slot;
-            const bool live = f < ch.n_frames && (ch.out_row + f) < p.row_limit;
-            const int64_t s0 = ch.pcm_off + (int64_t)(live ? f : 0) * p.shift;
+            const bool live = f < n_live;
+            if (f0 + 4 < n_live) pcm_issue<ALIGNED, NM>(nxt, rsrc, lane_off(f + 4));
 
             // ---- framing + window: z[l + 16m] = (w[2n] x[2n], w[2n+1] x[2n+1])
             float2 a[16];
+            const bool odd = !ALIGNED && ((odd0 + f * p.shift) & 1);
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 if (m < NM) {
                     uint32_t d;
                     if (ALIGNED) {
-                        int64_t idx = (s0 >> 1) + l + 16 * m;
-                        idx = idx < max_idx ? idx : max_idx;
-                        d = pcm32[idx];
+                        d = cur.d[m];
                     } else {
-                        int64_t s = s0 + 2 * (l + 16 * m);
-                        int64_t i0 = s >> 1;
-                        int64_t i1 = i0 + 1;
-                        i0 = i0 < max_idx ? i0 : max_idx;
-                        i1 = i1 < max_idx ? i1 : max_idx;
-                        uint32_t d0 = pcm32[i0], d1 = pcm32[i1];
-                        d = (s & 1) ? ((d0 >> 16) | (d1 << 16)) : d0;
+                        const uint32_t d0 = cur.d[2 * m], d1 = cur.d[2 * m + 1];
+                        d = odd ? ((d0 >> 16) | (d1 << 16)) : d0;
                     }
-                    float x0 = (float)(int)(short)(d & 0xffffu);
-                    float x1 = (float)((int)d >> 16);
-                    a[m] = make_float2(win[m].x * x0, win[m].y * x1);
+                    const float x0 = (float)(int)(short)(d & 0xffffu);
+                    const float x1 = (float)((int)d >> 16);
+                    const float2 w = s_win[m * 16 + l];
+                    a[m] = make_float2(w.x * x0, w.y * x1);
                 } else {
                     a[m] = make_float2(0.f, 0.f);
                 }
@@ -209,14 +259,18 @@ __global__ void __launch_bounds__(256) k_front512(FrontParams p)
             // ---- pass A + inter-pass twiddle
             fft16(a);
 #pragma unroll
-            for (int k = 1; k < 16; ++k) a[k] = cmul(a[k], tw[k]);
+            for (int k = 1; k < 16; ++k) a[k] = cmul(a[k], s_tw[k * 16 + l]);
 
-            // ---- 16x16 transpose through the frame slot
+            // ---- 16x16 transpose through the frame slot (XOR swizzle, see above)
 #pragma unroll
-            for (int k = 0; k < 16; ++k) ((float2 *)(xb + k * kXRow))[l] = a[k];
+            for (int k = 0; k < 16; ++k) ((float2 *)(xb + k * 32))[l ^ (k & 14)] = a[k];
             wave_sync();
 #pragma unroll
-            for (int j = 0; j < 16; ++j) a[j] = ((const float2 *)(xb + l * kXRow))[j];
+            for (int j = 0; j < 8; ++j) {
+                const float4 v = ((const float4 *)(xb + l * 32))[j ^ (l >> 1)];
+                a[2 * j] = make_float2(v.x, v.y);
+                a[2 * j + 1] = make_float2(v.z, v.w);
+            }
             wave_sync();
 
             // ---- pass B: a[pp] = Z[l + 16 pp]
@@ -227,25 +281,25 @@ __global__ void __launch_bounds__(256) k_front512(FrontParams p)
 #pragma unroll
             for (int pp = 0; pp < 16; ++pp) {
                 // partner value Z[256 - k]: lane (16-l)%16, register 15-pp (lane 0: register (16-pp)%16)
-                float zr = __shfl(a[15 - pp].x, partner, 64);
-                float zi = __shfl(a[15 - pp].y, partner, 64);
+                float zr = row_partner(a[15 - pp].x);
+                float zi = row_partner(a[15 - pp].y);
                 if (l == 0) {
                     zr = a[(16 - pp) & 15].x;
                     zi = a[(16 - pp) & 15].y;
                 }
-                const float2 cs = ((const float2 *)s_split)[l + 16 * pp];
+                const float2 cs = s_split[l + 16 * pp];
                 const float sr = a[pp].x + zr, si = a[pp].y - zi;
                 const float dr = a[pp].x - zr, di = a[pp].y + zi;
                 const float xr = sr + (cs.x * dr - cs.y * di);
                 const float xi = si + (cs.x * di + cs.y * dr);
-                mag[pp] = sqrtf(xr * xr + xi * xi) * scale;
+                mag[pp] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi) * scale;
             }
             // Nyquist bin: X[256] = Re Z[0] - Im Z[0]
             const float nyq = fabsf(a[0].x - a[0].y) * (2.0f * scale);
 
             if (TO_SPEC) {
                 if (live) {
-                    float *dst = p.spec + (ch.out_row + f) * (int64_t)p.spec_pitch;
+                    float *dst = p.spec + (out_row + f) * (int64_t)p.spec_pitch;
 #pragma unroll
                     for (int pp = 0; pp < 16; ++pp) dst[l + 16 * pp] = mag[pp];
                     if (l == 0) dst[256] = nyq;
@@ -255,15 +309,53 @@ __global__ void __launch_bounds__(256) k_front512(FrontParams p)
                 for (int pp = 0; pp < 16; ++pp) xb[l + 16 * pp] = mag[pp];
                 if (l == 0) xb[256] = nyq;
                 wave_sync();
-                // out_row pointer is only dereferenced by live frames
-                float *dst = p.feat + (ch.out_row + (live ? f : 0)) * (int64_t)p.feat_pitch;
+
+                // ---- mel filterbank: per round every lane walks one filter's bins in ascending
+                // order (mfcccpu.cpp:192-220); rounds are padded to a common length with zero weights
                 float *melbuf = xb + kMelOff;
-                // every lane runs the mel loops (uniform control flow for wave_sync); dead slots
-                // write to a scratch row inside the slot instead of HBM
-                mel_log_dct<16>(xb, melbuf, l, s_w0, s_w1, s_beg, p.dct ? s_dct : nullptr, nb, dl, cols,
-                                live ? dst : (xb + kMelOff + 136));
+                const float *wrow = s_melw + l * RS;
+                for (int r = 0; r < rounds; ++r) {
+                    const int L = p.mel_L[r];
+                    const float *mg = xb + s_mstart[r * 16 + l];
+                    const int fid = s_mfid[r * 16 + l];
+                    float acc = 0.f;
+                    for (int s = 0; s < L; s += 4) {
+                        const float4 w = *(const float4 *)(wrow + s);
+                        acc += w.x * mg[s];
+                        acc += w.y * mg[s + 1];
+                        acc += w.z * mg[s + 2];
+                        acc += w.w * mg[s + 3];
+                    }
+                    wrow += L;
+                    if (fid >= 0) melbuf[fid] = logf(fmaxf(acc, 1e-30f));
+                }
+                wave_sync();
+
+                // ---- DCT-II + lifter: out[c] = sum_m mel[m] * dct[m][c], ascending m (mfcccpu.cpp:222-232)
+                float *dst = p.feat + (out_row + (live ? f : 0)) * (int64_t)p.feat_pitch;
+                for (int c0 = 0; c0 < cols; c0 += 16) {
+                    const int cc = c0 + l;
+                    const bool act = cc < cols;
+                    float acc;
+                    if (p.dct) {
+                        const float *dm = s_dct + (act ? cc : 0) * DS;
+                        acc = 0.f;
+                        for (int m = 0; m < nb_pad; m += 4) {
+                            const float4 mv = *(const float4 *)(melbuf + m);
+                            const float4 dv = *(const float4 *)(dm + m);
+                            acc += mv.x * dv.x;
+                            acc += mv.y * dv.y;
+                            acc += mv.z * dv.z;
+                            acc += mv.w * dv.w;
+                        }
+                    } else {
+                        acc = melbuf[act ? cc : 0];
+                    }
+                    if (live && act) dst[cc] = acc;
+                }
                 wave_sync();
             }
+            cur = nxt;
         }
     }
 }
@@ -524,15 +616,19 @@ int num_cus()
     return g_num_cus;
 }
 
+} // namespace
+
 size_t front512_lds_bytes(const FrontParams &p)
 {
-    const int nb = p.num_banks;
-    size_t f = 2 * kBinsPad + 2 * kBinsPad;             // mel rows + split twiddles
-    f += (nb + 2 + 3) & ~3;                              // beg
-    f += ((p.dct ? nb * p.dct_len : 0) + 3) & ~3;        // dct
-    f += 4 * 4 * kXFrame;                                // 4 waves x 4 frame slots
+    size_t f = 512 + 512 + 2 * kBinsPad;                 // window pairs, pass twiddles, split twiddles
+    f += (size_t)16 * p.mel_row_stride;                  // per-lane mel weights
+    f += (size_t)32 * p.mel_rounds;                      // per-lane bin starts + filter ids
+    f += p.dct ? (size_t)p.cols * p.dct_stride : 0;      // transposed DCT matrix
+    f += 8 * 4 * kSlot;                                  // 8 waves x 4 frame slots
     return f * sizeof(float);
 }
+
+namespace {
 
 template <bool A, bool S, int NM>
 hipError_t launch512(const FrontParams &p, hipStream_t stream)
@@ -543,11 +639,11 @@ hipError_t launch512(const FrontParams &p, hipStream_t stream)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    int blocks = (p.n_chunks + 3) / 4;
-    const int cap = num_cus() * 4;
+    int blocks = (p.n_chunks + 7) / 8;
+    const int cap = num_cus() * 2;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_front512<A, S, NM>), dim3(blocks), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((k_front512<A, S, NM>), dim3(blocks), dim3(512), lds, stream, p);
     return hipGetLastError();
 }
 

@@ -99,3 +99,62 @@ void build_twiddles(int n, int count, std::vector<float> &t)
 }
 
 } // namespace mfx
+
+namespace mfx {
+
+static int stride_4odd(int n)
+{
+    int q = (n + 3) / 4;
+    if ((q & 1) == 0) ++q;
+    return 4 * q;
+}
+
+bool build_mel_lane_plan(const MelTable &t, int num_banks, int fft_size, int max_read_bin, MelLanePlan &out)
+{
+    std::vector<int> order(num_banks);
+    for (int m = 0; m < num_banks; ++m) order[m] = m;
+    auto span = [&](int m) { return t.beg[m + 2] - t.beg[m]; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return span(a) > span(b); });
+    out.rounds = (num_banks + 15) / 16;
+    if (out.rounds > 8) return false;
+    int total = 0;
+    for (int r = 0; r < out.rounds; ++r) {
+        int longest = 0;
+        for (int j = 0; j < 16 && r * 16 + j < num_banks; ++j) longest = std::max(longest, span(order[r * 16 + j]));
+        out.L[r] = std::max(4, (longest + 3) & ~3);
+        total += out.L[r];
+    }
+    out.row_stride = stride_4odd(total);
+    out.w.assign((size_t)16 * out.row_stride, 0.0f);
+    out.start.assign((size_t)16 * out.rounds, 0);
+    out.fid.assign((size_t)16 * out.rounds, -1);
+    int base = 0;
+    for (int r = 0; r < out.rounds; ++r) {
+        for (int j = 0; j < 16; ++j) {
+            const int idx = r * 16 + j;
+            if (idx >= num_banks) continue;
+            const int m = order[idx];
+            const int b0 = t.beg[m], b1 = t.beg[m + 2];
+            if (b0 + out.L[r] - 1 > max_read_bin) return false;
+            out.start[r * 16 + j] = b0;
+            out.fid[r * 16 + j] = m;
+            const float *row = t.weights.data() + (size_t)(m & 1) * fft_size;
+            float *dst = out.w.data() + (size_t)j * out.row_stride + base;
+            for (int k = b0; k < b1; ++k) dst[k - b0] = row[k];
+        }
+        base += out.L[r];
+    }
+    return true;
+}
+
+void build_dct_transposed(const std::vector<float> &dct, int num_banks, int dct_len, int &stride, int &nb_pad,
+                          std::vector<float> &out)
+{
+    nb_pad = (num_banks + 3) & ~3;
+    stride = stride_4odd(nb_pad);
+    out.assign((size_t)dct_len * stride, 0.0f);
+    for (int m = 0; m < num_banks; ++m)
+        for (int c = 0; c < dct_len; ++c) out[(size_t)c * stride + m] = dct[(size_t)m * dct_len + c];
+}
+
+} // namespace mfx

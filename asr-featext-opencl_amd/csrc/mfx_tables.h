@@ -38,3 +38,29 @@ void build_dct_matrix(int num_banks, int ceps_len, bool want_c0, float lift_coef
 void build_twiddles(int n, int count, std::vector<float> &re_im_interleaved);
 
 } // namespace mfx
+
+namespace mfx {
+
+// Work plan of the mel stage of the 512-point kernel: the filters are dealt to the 16 lanes that
+// share a frame, `rounds` at a time (longest filters first so that a round's padding is small).
+// Lane j's weights for round r start at w[j * row_stride + sum(L[0..r))], cover bins
+// [start[r][j], start[r][j] + L[r]) and are zero outside the filter's own span.
+struct MelLanePlan {
+    int rounds = 0;
+    int row_stride = 0;            // floats; a multiple of 4 with row_stride / 4 odd (LDS banks)
+    int L[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<float> w;          // [16][row_stride]
+    std::vector<int32_t> start;    // [rounds][16]
+    std::vector<int32_t> fid;      // [rounds][16], -1 = idle lane
+};
+
+// false when the plan does not fit the kernel's limits (more than 8 rounds, or a padded span that
+// would read past `max_read_bin`)
+bool build_mel_lane_plan(const MelTable &t, int num_banks, int fft_size, int max_read_bin, MelLanePlan &out);
+
+// Transposed, padded DCT matrix for the 512-point kernel: [cols][stride], stride / 4 odd,
+// row c = column c of the [num_banks][dct_len] matrix followed by zeros.
+void build_dct_transposed(const std::vector<float> &dct, int num_banks, int dct_len, int &stride, int &nb_pad,
+                          std::vector<float> &out);
+
+} // namespace mfx

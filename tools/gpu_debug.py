@@ -47,6 +47,10 @@ def main():
     mag_o = np.sqrt(fft[:, :257, 0] ** 2 + fft[:, :257, 1] ** 2) / 512
     mag_m = m.debug_read(3).reshape(wcnd, -1)[:, :257]
     print("magnitude rel err", rel(mag_m, mag_o), "worst bin", np.unravel_index(np.abs(mag_m - mag_o).argmax(), mag_o.shape))
+    err = np.abs(mag_m - mag_o) / mag_o.max()
+    print("err by frame (first 8):", np.round(err.max(1)[:8], 4))
+    print("err by k mod 16:", np.round([err[:, r::16].max() for r in range(16)], 4))
+    print("err by k // 16:", np.round([err[:, 16 * p:16 * p + 16].max() for p in range(16)], 4), "nyq", err[:, 256].max())
     o.apply()
     m.apply()
     a, b = o.get_output_data(n_o), m.get_output_data(n_m)
