@@ -71,7 +71,9 @@ struct mfx_handle {
     DevBuf<float> d_window, d_winpair, d_twid_pass, d_twid_half, d_twid_split, d_mel_w, d_dct;
     DevBuf<int32_t> d_mel_beg;
     // 512-point kernel: per-lane mel plan + transposed DCT matrix
-    DevBuf<float> d_mel_lane_w, d_dct_t;
+    DevBuf<int32_t> d_work_counter;
+    DevBuf<float> d_mel_lane_w, d_dct_t, d_dct_lane_w;
+    int dct_lane_stride = 0;
     DevBuf<int32_t> d_mel_lane_start, d_mel_lane_fid;
     MelLanePlan plan;
     int dct_stride = 0, nb_pad = 0;
@@ -156,8 +158,13 @@ int refresh_mel(mfx_handle *h)
     HIP_TRY(h, upload(h->d_mel_w, t.weights));
     HIP_TRY(h, upload(h->d_mel_beg, t.beg));
     h->fused_ok = false;
-    if (h->fast512 && build_mel_lane_plan(t, h->nb, h->W2, /*max_read_bin=*/511, h->plan)) {
+    if (h->fast512 && build_mel_lane_plan(t, h->nb, h->W2, /*max_read_bin=*/511 - 32, h->plan)) {
         HIP_TRY(h, upload(h->d_mel_lane_w, h->plan.w));
+        if (h->ceps > 0 && h->cols <= 16) { // fused mel + DCT with the DPP reduction
+            std::vector<float> rows;
+            build_dct_lane_rows(h->plan, h->h_dct, h->dl, h->dct_lane_stride, rows);
+            HIP_TRY(h, upload(h->d_dct_lane_w, rows));
+        }
         HIP_TRY(h, upload(h->d_mel_lane_start, h->plan.start));
         HIP_TRY(h, upload(h->d_mel_lane_fid, h->plan.fid));
         FrontParams probe;
@@ -194,7 +201,10 @@ void fill_front(const mfx_handle *h, FrontParams &p)
     p.mel_rounds = h->plan.rounds;
     p.mel_row_stride = h->plan.row_stride;
     for (int i = 0; i < 8; ++i) p.mel_L[i] = h->plan.L[i];
-    p.dct_stride = h->dct_stride;
+    p.work_counter = h->d_work_counter.p;
+    p.dct_lane_w = h->d_dct_lane_w.p;
+    p.dct_mode = (h->ceps > 0 && h->cols <= 16 && h->d_dct_lane_w.p) ? 1 : 0;
+    p.dct_stride = p.dct_mode == 1 ? h->dct_lane_stride : h->dct_stride;
     p.nb_pad = h->nb_pad > 0 ? h->nb_pad : ((h->nb + 3) & ~3);
 }
 
@@ -305,6 +315,8 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_mel_beg.release();
     h->d_mel_lane_w.release();
     h->d_dct_t.release();
+    h->d_dct_lane_w.release();
+    h->d_work_counter.release();
     h->d_mel_lane_start.release();
     h->d_mel_lane_fid.release();
     h->d_carry[0].release();
@@ -389,6 +401,7 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(MFX_ERR_DEVICE);
     h->own_stream = true;
 
+    if (h->d_work_counter.alloc(4) != hipSuccess) return bail(MFX_ERR_DEVICE);
     // ---- constant tables
     {
         std::vector<float> tw;
@@ -418,6 +431,7 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
             std::vector<float> m;
             build_dct_matrix(h->nb, h->ceps, cfg->want_c0 != 0, cfg->lift_coef, m);
             if (upload(h->d_dct, m) != hipSuccess) return bail(MFX_ERR_DEVICE);
+            h->h_dct = m;
             if (h->fast512) {
                 std::vector<float> mt;
                 build_dct_transposed(m, h->nb, h->dl, h->dct_stride, h->nb_pad, mt);
@@ -879,6 +893,7 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
     p.feat_pitch = h->width;
 
     if (h->fast512 && h->fused_ok) {
+        p.spec = h->d_spec.p; // unused by the fused kernel; a -DMFX_STAMPS dev build drops its cycle sums here
         ProfScope ps(h);
         HIP_TRY(h, launch_front512(p, /*to_spectrum=*/false, h->batch_aligned, h->nm16, h->stream));
     } else {
@@ -1017,6 +1032,10 @@ extern "C" int64_t mfx_debug_read(mfx_handle *h, int kind, void *dst, int64_t ds
     case 3:
         src = h->d_spec.p;
         count = (int64_t)h->block_wcnd * h->spec_pitch;
+        break;
+    case 4: // raw head of the spectrum buffer (dev builds park in-kernel stamps there)
+        src = h->d_spec.p;
+        count = std::min<int64_t>(dst_bytes / 4, (int64_t)h->d_spec.n);
         break;
     default:
         return MFX_ERR_ARG;

@@ -126,8 +126,7 @@ __device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int
 // 0) one iteration ahead of its use.
 // ------------------------------------------------------------------------------------------------
 constexpr int kSlot = 512;    // dwords per frame slot
-constexpr int kMelOff = 260;  // mel scratch offset inside the slot (after 257 magnitudes)
-constexpr int kBinsPad = 264;
+constexpr int kMelOff = 304;  // mel scratch offset inside the slot (after 32 + 257 magnitudes)
 
 // y[l] = x[(16 - l) & 15] inside every row of 16 lanes: mirror, then rotate right by one
 __device__ __forceinline__ float row_partner(float x)
@@ -135,6 +134,44 @@ __device__ __forceinline__ float row_partner(float x)
     int t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, true); // row_mirror
     t = __builtin_amdgcn_update_dpp(0, t, 0x121, 0xf, 0xf, true);                      // row_ror:1
     return __int_as_float(t);
+}
+
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ float dpp_mov(float old, float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), CTRL, 0xf, BANK_MASK, false));
+}
+
+// Sum 16 values over the 16 lanes of a DPP row; lane c returns the total of v[c].
+// Butterfly: at distance 1, 2, 4, 8 each lane keeps the half of its values whose index bit equals
+// its own lane bit and adds the partner's copy of that half.
+__device__ __forceinline__ float row_reduce16(const float (&v)[16], int l)
+{
+    const bool b0 = l & 1, b1 = l & 2, b2 = l & 4, b3 = l & 8;
+    float w[8], x[4], y[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float keep = b0 ? v[2 * i + 1] : v[2 * i];
+        const float send = b0 ? v[2 * i] : v[2 * i + 1];
+        w[i] = keep + dpp_mov<0xB1, 0xf>(0.f, send); // quad_perm [1,0,3,2]: lane ^ 1
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b1 ? w[2 * i + 1] : w[2 * i];
+        const float send = b1 ? w[2 * i] : w[2 * i + 1];
+        x[i] = keep + dpp_mov<0x4E, 0xf>(0.f, send); // quad_perm [2,3,0,1]: lane ^ 2
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b2 ? x[2 * i + 1] : x[2 * i];
+        const float send = b2 ? x[2 * i] : x[2 * i + 1];
+        float t = dpp_mov<0x104, 0x5>(0.f, send);   // row_shl:4 into banks 0,2: from lane + 4
+        t = dpp_mov<0x114, 0xA>(t, send);           // row_shr:4 into banks 1,3: from lane - 4
+        y[i] = keep + t;
+    }
+    const float keep = b3 ? y[1] : y[0];
+    const float send = b3 ? y[0] : y[1];
+    return keep + dpp_mov<0x128, 0xf>(0.f, send);   // row_ror:8: lane ^ 8
 }
 
 template <bool ALIGNED, int NM>
@@ -157,6 +194,31 @@ __device__ __forceinline__ void pcm_issue(PcmRegs<ALIGNED, NM> &r, __amdgpu_buff
     }
 }
 
+// Natural log of a positive normal float.  v_log_f32 is accurate to 1 ulp of log2(x); the product
+// with ln 2 keeps the absolute error near 1e-7 * |log x|, far inside the parity tolerance (the
+// reference uses libm logf, mfcccpu.cpp:212).  -DMFX_EXACT_LOG selects the library logf instead.
+#ifdef MFX_EXACT_LOG
+#define MFX_LOG(x) logf(x)
+#else
+#define MFX_LOG(x) (__builtin_amdgcn_logf(x) * 0.69314718055994530942f)
+#endif
+
+// Dev-only in-kernel stamps (-DMFX_STAMPS): per-wave cycle sums per phase, written by lane 0 to
+// p.spec (which is unused by the fused path).  Never part of a timed build.
+#ifdef MFX_STAMPS
+#define MFX_STAMP(i)                                                                   \
+    do {                                                                               \
+        unsigned long long t_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        st_acc[i] += t_ - st_last;                                                     \
+        st_last = t_;                                                                  \
+    } while (0)
+#else
+#define MFX_STAMP(i)
+#endif
+
 template <bool ALIGNED, bool TO_SPEC, int NM>
 __global__ void __launch_bounds__(512, 4) k_front512(FrontParams p)
 {
@@ -171,17 +233,18 @@ __global__ void __launch_bounds__(512, 4) k_front512(FrontParams p)
     const int rounds = p.mel_rounds, RS = p.mel_row_stride, DS = p.dct_stride, nb_pad = p.nb_pad;
     float2 *s_win = (float2 *)smem;                  // [16 m][16 l]
     float2 *s_tw = s_win + 256;                      // [16 k][16 l]
-    float2 *s_split = s_tw + 256;                    // [264]
-    float *s_melw = (float *)(s_split + kBinsPad);   // [16][RS]
+    float2 *s_split = s_tw + 256;                    // [264], natural bin order k = l + 16 p
+    float *s_melw = (float *)(s_split + 264);        // [16][RS]
     int *s_mstart = (int *)(s_melw + 16 * RS);       // [rounds][16]
     int *s_mfid = s_mstart + 16 * rounds;            // [rounds][16]
     float *s_dct = (float *)(s_mfid + 16 * rounds);  // [cols][DS]
-    const int dct_floats = p.dct ? cols * DS : 0;
+    const int dct_floats = p.dct ? (p.dct_mode == 1 ? 16 : cols) * DS : 0;
     float *s_wave = s_dct + dct_floats + wave * (4 * kSlot);
     float *xb = s_wave + slot * kSlot;
 
     for (int i = tid; i < 256; i += 512) {
-        // HBM tables are [lane][m]; the LDS copies are [m][lane] so that one row is read per instruction
+        // HBM tables are [lane][m]; the LDS copies are [m][lane]: one instruction reads one row,
+        // 16 consecutive 8-byte words (the 4 frames of a wave read the same words: broadcast)
         s_win[i] = ((const float2 *)p.winpair)[(i & 15) * 16 + (i >> 4)];
         s_tw[i] = ((const float2 *)p.twid_pass)[(i & 15) * 16 + (i >> 4)];
     }
@@ -192,7 +255,7 @@ __global__ void __launch_bounds__(512, 4) k_front512(FrontParams p)
             s_mstart[i] = p.mel_lane_start[i];
             s_mfid[i] = p.mel_lane_fid[i];
         }
-        for (int i = tid; i < dct_floats; i += 512) s_dct[i] = p.dct_t[i];
+        for (int i = tid; i < dct_floats; i += 512) s_dct[i] = (p.dct_mode == 1 ? p.dct_lane_w : p.dct_t)[i];
     }
     // the slots are read (times zero weights) before every word has been written once: make them finite
     for (int i = lane; i < 4 * kSlot; i += 64) s_wave[i] = 0.f;
@@ -200,7 +263,19 @@ __global__ void __launch_bounds__(512, 4) k_front512(FrontParams p)
 
     const float scale = p.scale;
 
-    for (int c = blockIdx.x * 8 + wave; c < p.n_chunks; c += gridDim.x * 8) {
+#ifdef MFX_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_rt0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt0)::"memory");
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
+    // Chunks are handed out dynamically (one relaxed device-scope atomic per 64 frames, fetched one
+    // chunk ahead): waves that share a SIMD with slower partners would otherwise finish up to 40 %
+    // apart under a static split.
+    // The first chunk of every wave is its own index (no atomic burst at start-up); the shared
+    // counter, preset to the number of waves in the grid, hands out the rest.
+    int c = blockIdx.x * 8 + wave, c_next = 0;
+    for (; c < p.n_chunks; c = c_next) {
+        if (lane == 0) c_next = __hip_atomic_fetch_add(p.work_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // wave-uniform chunk descriptor -> scalar registers
         const Chunk *chp = p.chunks + c;
         const int64_t pcm_off = chp->pcm_off;
@@ -232,8 +307,12 @@ __global__ void __launch_bounds__(512, 4) k_front512(FrontParams p)
         for (int f0 = 0; f0 < n_live; f0 += 4) {
             const int f = f0 + slot;
             const bool live = f < n_live;
-            if (f0 + 4 < n_live) pcm_issue<ALIGNED, NM>(nxt, rsrc, lane_off(f + 4));
+            // Prefetch the next iteration unconditionally: a conditional issue would make the number of
+            // loads in flight path-dependent and force the compiler to wait for vmcnt(0) here.  Past the
+            // chunk's last frame this reads the following frames (or 0 beyond the array): harmless.
+            pcm_issue<ALIGNED, NM>(nxt, rsrc, lane_off(f + 4));
 
+            MFX_STAMP(0);
             // ---- framing + window: z[l + 16m] = (w[2n] x[2n], w[2n+1] x[2n+1])
             float2 a[16];
             const bool odd = !ALIGNED && ((odd0 + f * p.shift) & 1);
@@ -256,11 +335,13 @@ __global__ void __launch_bounds__(512, 4) k_front512(FrontParams p)
                 }
             }
 
+            MFX_STAMP(1);
             // ---- pass A + inter-pass twiddle
             fft16(a);
 #pragma unroll
             for (int k = 1; k < 16; ++k) a[k] = cmul(a[k], s_tw[k * 16 + l]);
 
+            MFX_STAMP(2);
             // ---- 16x16 transpose through the frame slot (XOR swizzle, see above)
 #pragma unroll
             for (int k = 0; k < 16; ++k) ((float2 *)(xb + k * 32))[l ^ (k & 14)] = a[k];
@@ -273,11 +354,20 @@ __global__ void __launch_bounds__(512, 4) k_front512(FrontParams p)
             }
             wave_sync();
 
+            MFX_STAMP(3);
             // ---- pass B: a[pp] = Z[l + 16 pp]
+#if !defined(MFX_ABLATE) || MFX_ABLATE < 3
             fft16(a);
+#endif
 
+            MFX_STAMP(4);
             // ---- real split + magnitude
             float mag[16];
+#if defined(MFX_ABLATE) && MFX_ABLATE >= 2
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp) mag[pp] = a[pp].x + a[pp].y;
+            const float nyq = 0.f;
+#else
 #pragma unroll
             for (int pp = 0; pp < 16; ++pp) {
                 // partner value Z[256 - k]: lane (16-l)%16, register 15-pp (lane 0: register (16-pp)%16)
@@ -296,7 +386,9 @@ __global__ void __launch_bounds__(512, 4) k_front512(FrontParams p)
             }
             // Nyquist bin: X[256] = Re Z[0] - Im Z[0]
             const float nyq = fabsf(a[0].x - a[0].y) * (2.0f * scale);
+#endif
 
+            MFX_STAMP(5);
             if (TO_SPEC) {
                 if (live) {
                     float *dst = p.spec + (out_row + f) * (int64_t)p.spec_pitch;
@@ -305,59 +397,136 @@ __global__ void __launch_bounds__(512, 4) k_front512(FrontParams p)
                     if (l == 0) dst[256] = nyq;
                 }
             } else {
+#if defined(MFX_ABLATE) && MFX_ABLATE >= 1
+                {   // dev-only: stop after the magnitudes, keep them live
+                    float acc = nyq;
 #pragma unroll
-                for (int pp = 0; pp < 16; ++pp) xb[l + 16 * pp] = mag[pp];
-                if (l == 0) xb[256] = nyq;
+                    for (int pp = 0; pp < 16; ++pp) acc += mag[pp];
+                    float *dstx = p.feat + (out_row + (live ? f : 0)) * (int64_t)p.feat_pitch;
+                    if (live && l < cols) dstx[l] = acc;
+                    cur = nxt;
+                    continue;
+                }
+#endif
+                // odd slots keep their magnitudes 32 dwords further in: the two slots of a 32-lane
+                // LDS access group then sit on complementary bank pairs for the b64 mel reads
+                float *mg0 = xb + 32 * (slot & 1);
+#pragma unroll
+                for (int pp = 0; pp < 16; ++pp) mg0[l + 16 * pp] = mag[pp];
+                if (l == 0) mg0[256] = nyq;
                 wave_sync();
 
                 // ---- mel filterbank: per round every lane walks one filter's bins in ascending
-                // order (mfcccpu.cpp:192-220); rounds are padded to a common length with zero weights
-                float *melbuf = xb + kMelOff;
+                // order (mfcccpu.cpp:192-220).  Rounds are padded to a common even length with zero
+                // weights; starts are even so that two bins come per ds_read_b64, and the host picks
+                // them so that the 16 lanes of a slot (and the neighbouring slot, skewed by 32 dwords)
+                // fall on distinct bank pairs.
                 const float *wrow = s_melw + l * RS;
-                for (int r = 0; r < rounds; ++r) {
-                    const int L = p.mel_L[r];
-                    const float *mg = xb + s_mstart[r * 16 + l];
-                    const int fid = s_mfid[r * 16 + l];
-                    float acc = 0.f;
-                    for (int s = 0; s < L; s += 4) {
-                        const float4 w = *(const float4 *)(wrow + s);
-                        acc += w.x * mg[s];
-                        acc += w.y * mg[s + 1];
-                        acc += w.z * mg[s + 2];
-                        acc += w.w * mg[s + 3];
-                    }
-                    wrow += L;
-                    if (fid >= 0) melbuf[fid] = logf(fmaxf(acc, 1e-30f));
-                }
-                wave_sync();
-
-                // ---- DCT-II + lifter: out[c] = sum_m mel[m] * dct[m][c], ascending m (mfcccpu.cpp:222-232)
                 float *dst = p.feat + (out_row + (live ? f : 0)) * (int64_t)p.feat_pitch;
-                for (int c0 = 0; c0 < cols; c0 += 16) {
-                    const int cc = c0 + l;
-                    const bool act = cc < cols;
-                    float acc;
-                    if (p.dct) {
-                        const float *dm = s_dct + (act ? cc : 0) * DS;
-                        acc = 0.f;
-                        for (int m = 0; m < nb_pad; m += 4) {
-                            const float4 mv = *(const float4 *)(melbuf + m);
-                            const float4 dv = *(const float4 *)(dm + m);
-                            acc += mv.x * dv.x;
-                            acc += mv.y * dv.y;
-                            acc += mv.z * dv.z;
-                            acc += mv.w * dv.w;
+                if (p.dct_mode == 1) {
+                    // DCT-II + lifter fused into the mel rounds: lane j adds its filter's log energy
+                    // times row fid of the DCT matrix into 16 per-lane partial sums, which a 4-step
+                    // DPP butterfly then reduces over the frame's 16 lanes (lane c ends with output c).
+                    // Round lengths are multiples of 16 bins: each trip issues its 12 LDS reads back to
+                    // back before the 16 dependent FMAs, so the read latency is paid once per trip.
+                    float part[16];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) part[c] = 0.f;
+                    const float *drow = s_dct + l * DS;
+                    for (int r = 0; r < rounds; ++r) {
+                        const int L = p.mel_L[r];
+                        const float *mg = mg0 + s_mstart[r * 16 + l];
+                        float4 dv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dv[q] = *(const float4 *)(drow + r * 16 + 4 * q);
+                        float acc = 0.f;
+                        for (int s = 0; s < L; s += 8) {
+                            float4 w[2];
+                            float2 mm[4];
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) w[q] = *(const float4 *)(wrow + s + 4 * q);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) mm[q] = *(const float2 *)(mg + s + 2 * q);
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                acc += w[q].x * mm[2 * q].x;
+                                acc += w[q].y * mm[2 * q].y;
+                                acc += w[q].z * mm[2 * q + 1].x;
+                                acc += w[q].w * mm[2 * q + 1].y;
+                            }
                         }
-                    } else {
-                        acc = melbuf[act ? cc : 0];
+                        wrow += L;
+                        const float e = MFX_LOG(fmaxf(acc, 1e-30f));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            part[4 * q + 0] += e * dv[q].x;
+                            part[4 * q + 1] += e * dv[q].y;
+                            part[4 * q + 2] += e * dv[q].z;
+                            part[4 * q + 3] += e * dv[q].w;
+                        }
                     }
-                    if (live && act) dst[cc] = acc;
+                    const float outv = row_reduce16(part, l);
+                    if (live && l < cols) dst[l] = outv;
+                } else {
+                    float *melbuf = xb + kMelOff;
+                    for (int r = 0; r < rounds; ++r) {
+                        const int L = p.mel_L[r];
+                        const float *mg = mg0 + s_mstart[r * 16 + l];
+                        const int fid = s_mfid[r * 16 + l];
+                        float acc = 0.f;
+                        for (int s = 0; s < L; s += 4) {
+                            const float4 w = *(const float4 *)(wrow + s);
+                            const float2 m0 = *(const float2 *)(mg + s);
+                            const float2 m1 = *(const float2 *)(mg + s + 2);
+                            acc += w.x * m0.x;
+                            acc += w.y * m0.y;
+                            acc += w.z * m1.x;
+                            acc += w.w * m1.y;
+                        }
+                        wrow += L;
+                        if (fid >= 0) melbuf[fid] = MFX_LOG(fmaxf(acc, 1e-30f));
+                    }
+                    wave_sync();
+                    // ---- DCT-II + lifter: out[c] = sum_m mel[m] * dct[m][c], ascending m (mfcccpu.cpp:222-232)
+                    for (int c0 = 0; c0 < cols; c0 += 16) {
+                        const int cc = c0 + l;
+                        const bool act = cc < cols;
+                        float acc;
+                        if (p.dct) {
+                            const float *dm = s_dct + (act ? cc : 0) * DS;
+                            acc = 0.f;
+                            for (int m = 0; m < nb_pad; m += 4) {
+                                const float4 mv = *(const float4 *)(melbuf + m);
+                                const float4 dv = *(const float4 *)(dm + m);
+                                acc += mv.x * dv.x;
+                                acc += mv.y * dv.y;
+                                acc += mv.z * dv.z;
+                                acc += mv.w * dv.w;
+                            }
+                        } else {
+                            acc = melbuf[act ? cc : 0];
+                        }
+                        if (live && act) dst[cc] = acc;
+                    }
                 }
                 wave_sync();
             }
+            MFX_STAMP(6);
             cur = nxt;
         }
+        // keep the atomic's result in flight until here (an opaque use pins the broadcast below it)
+        asm volatile("" : "+v"(c_next));
+        c_next = __builtin_amdgcn_readfirstlane(c_next);
     }
+#ifdef MFX_STAMPS
+    if (lane == 0 && p.spec) {
+        unsigned long long *o = (unsigned long long *)p.spec + (size_t)(blockIdx.x * 8 + wave) * 8;
+        unsigned long long st_rt1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1)::"memory");
+        st_acc[7] = st_rt1 - st_rt0; // 100 MHz ticks over the same span
+        for (int i = 0; i < 8; ++i) o[i] = st_acc[i];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -620,10 +789,10 @@ int num_cus()
 
 size_t front512_lds_bytes(const FrontParams &p)
 {
-    size_t f = 512 + 512 + 2 * kBinsPad;                 // window pairs, pass twiddles, split twiddles
+    size_t f = 512 + 512 + 2 * 264;                      // window pairs, pass twiddles, split twiddles
     f += (size_t)16 * p.mel_row_stride;                  // per-lane mel weights
     f += (size_t)32 * p.mel_rounds;                      // per-lane bin starts + filter ids
-    f += p.dct ? (size_t)p.cols * p.dct_stride : 0;      // transposed DCT matrix
+    f += p.dct ? (size_t)(p.dct_mode == 1 ? 16 : p.cols) * p.dct_stride : 0; // DCT table (either layout)
     f += 8 * 4 * kSlot;                                  // 8 waves x 4 frame slots
     return f * sizeof(float);
 }
@@ -643,6 +812,9 @@ hipError_t launch512(const FrontParams &p, hipStream_t stream)
     const int cap = num_cus() * 2;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
+    // work counter := number of waves in the grid (hipMemsetD32Async writes one 32-bit word)
+    hipError_t e0 = hipMemsetD32Async((hipDeviceptr_t)p.work_counter, blocks * 8, 1, stream);
+    if (e0 != hipSuccess) return e0;
     hipLaunchKernelGGL((k_front512<A, S, NM>), dim3(blocks), dim3(512), lds, stream, p);
     return hipGetLastError();
 }

@@ -117,34 +117,69 @@ bool build_mel_lane_plan(const MelTable &t, int num_banks, int fft_size, int max
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return span(a) > span(b); });
     out.rounds = (num_banks + 15) / 16;
     if (out.rounds > 8) return false;
-    int total = 0;
-    for (int r = 0; r < out.rounds; ++r) {
-        int longest = 0;
-        for (int j = 0; j < 16 && r * 16 + j < num_banks; ++j) longest = std::max(longest, span(order[r * 16 + j]));
-        out.L[r] = std::max(4, (longest + 3) & ~3);
-        total += out.L[r];
-    }
-    out.row_stride = stride_4odd(total);
-    out.w.assign((size_t)16 * out.row_stride, 0.0f);
     out.start.assign((size_t)16 * out.rounds, 0);
     out.fid.assign((size_t)16 * out.rounds, -1);
-    int base = 0;
+    int total = 0;
     for (int r = 0; r < out.rounds; ++r) {
+        // Starts are even (two bins per 8-byte LDS read).  The 16 lanes of a frame read at
+        // start + s simultaneously; they fall on distinct bank pairs when (start / 2) mod 16 differs
+        // from lane to lane, so a clashing filter begins up to a few pairs early (zero weights).
+        bool used[16] = {false};
+        int longest = 0;
         for (int j = 0; j < 16; ++j) {
             const int idx = r * 16 + j;
             if (idx >= num_banks) continue;
             const int m = order[idx];
             const int b0 = t.beg[m], b1 = t.beg[m + 2];
-            if (b0 + out.L[r] - 1 > max_read_bin) return false;
-            out.start[r * 16 + j] = b0;
+            int start = b0 & ~1;
+            // a few pairs early at most: a longer shift costs more in padded bins (every lane runs
+            // the round's longest span) than the two-way bank conflict it would avoid
+            for (int d = 0; d < 4; ++d) {
+                const int cand = (b0 & ~1) - 2 * d;
+                if (cand < 0) break;
+                if (!used[(cand >> 1) & 15]) {
+                    start = cand;
+                    break;
+                }
+            }
+            used[(start >> 1) & 15] = true;
+            out.start[r * 16 + j] = start;
             out.fid[r * 16 + j] = m;
+            longest = std::max(longest, b1 - start);
+        }
+        out.L[r] = std::max(8, (longest + 7) & ~7);
+        total += out.L[r];
+    }
+    out.row_stride = stride_4odd(total);
+    out.w.assign((size_t)16 * out.row_stride, 0.0f);
+    int base = 0;
+    for (int r = 0; r < out.rounds; ++r) {
+        for (int j = 0; j < 16; ++j) {
+            const int m = out.fid[r * 16 + j];
+            if (m < 0) continue;
+            const int start = out.start[r * 16 + j];
+            if (start + out.L[r] - 1 > max_read_bin) return false;
             const float *row = t.weights.data() + (size_t)(m & 1) * fft_size;
             float *dst = out.w.data() + (size_t)j * out.row_stride + base;
-            for (int k = b0; k < b1; ++k) dst[k - b0] = row[k];
+            for (int k = t.beg[m]; k < t.beg[m + 2]; ++k) dst[k - start] = row[k];
         }
         base += out.L[r];
     }
     return true;
+}
+
+void build_dct_lane_rows(const MelLanePlan &plan, const std::vector<float> &dct, int dct_len, int &stride,
+                         std::vector<float> &out)
+{
+    stride = stride_4odd(plan.rounds * 16);
+    out.assign((size_t)16 * stride, 0.0f);
+    for (int r = 0; r < plan.rounds; ++r)
+        for (int j = 0; j < 16; ++j) {
+            const int m = plan.fid[r * 16 + j];
+            if (m < 0) continue;
+            for (int c = 0; c < dct_len && c < 16; ++c)
+                out[(size_t)j * stride + r * 16 + c] = dct[(size_t)m * dct_len + c];
+        }
 }
 
 void build_dct_transposed(const std::vector<float> &dct, int num_banks, int dct_len, int &stride, int &nb_pad,

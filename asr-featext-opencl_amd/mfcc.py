@@ -62,7 +62,8 @@ EXPORTED_SYMBOLS = (
 
 
 def library_path():
-    return os.path.join(_HERE, "libmfcchip.so")
+    # MFX_LIB: developer override to A/B an experimental build of the same ABI
+    return os.environ.get("MFX_LIB") or os.path.join(_HERE, "libmfcchip.so")
 
 
 _lib = None

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Collects rocprofv3 PMC passes for the bench (one counter group per run; --pmc is never combined
+# with trace domains other than the kernel trace).  Usage on the GPU box:  tools/pmc_run.sh <tag> [bench args]
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=${1:-pmc}; shift || true
+OUT=$R/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_UNALIGNED_STALL SQ_BUSY_CYCLES" \
+           "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/p$i" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline "$@" > "$OUT/p$i.log" 2>&1 || echo "pass $i failed"
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections, json
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row.get("Kernel_Name", "")
+        if "mfx::" not in k: continue
+        short = "k_front512" if "k_front512" in k else "k_delta" if "k_delta" in k else k[:40]
+        agg[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+res = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
+json.dump(res, open(out + "/pmc_summary.json", "w"), indent=1, sort_keys=True)
+print(json.dumps(res, indent=1, sort_keys=True))
+PY
