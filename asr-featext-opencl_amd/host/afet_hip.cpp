@@ -1,0 +1,198 @@
+// afet_hip.cpp -- command-line driver over MfccHip: the reference's per-file loop
+// (process_files_worker, ASR_OCL.cpp:109-338) with its own minimal RIFF/PCM16 reader in place of
+// libsndfile and the option names of the reference's (commented-out) option table
+// (ASR_OCL.cpp:569-669).  Output is the reference's text format (ASR_OCL.cpp:252-260):
+//     | <frame time> | v0 | v1 | ... |
+//
+//   afet_hip [options] in1.wav out1.txt [in2.wav out2.txt ...]
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "afet_param.h"
+
+namespace {
+
+struct Options {
+    float window_ms = 25.f, shift_ms = 10.f;
+    int banks = 15, ceps = 12, norm = 2, dyn = 0, l1 = 3, l2 = 3;   // reference main() defaults (ASR_OCL.cpp:560)
+    float low = 64.f, high = 0.f, lift = 22.f;
+    bool c0 = true, norm_after_dyn = true;
+    float alpha_min = 1.f, alpha_max = 1.f, alpha_step = 1.f;
+    int sample_limit = 10000000, device = 0;
+    bool bug_compat = true;
+};
+
+struct Wav {
+    int sample_rate = 0, channels = 0;
+    std::vector<int16_t> pcm; // interleaved
+};
+
+uint32_t rd32(const unsigned char *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint16_t rd16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+Wav read_wav(const std::string &path)
+{
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("Can't open \"" + path + "\"");
+    std::vector<unsigned char> b;
+    unsigned char buf[65536];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) b.insert(b.end(), buf, buf + n);
+    std::fclose(f);
+    if (b.size() < 12 || std::memcmp(b.data(), "RIFF", 4) != 0 || std::memcmp(b.data() + 8, "WAVE", 4) != 0)
+        throw std::runtime_error("\"" + path + "\" is not a RIFF/WAVE file");
+    Wav w;
+    size_t pos = 12;
+    bool have_fmt = false;
+    while (pos + 8 <= b.size()) {
+        const uint32_t sz = rd32(&b[pos + 4]);
+        const unsigned char *body = &b[pos + 8];
+        if (std::memcmp(&b[pos], "fmt ", 4) == 0 && sz >= 16) {
+            if (rd16(body) != 1 || rd16(body + 14) != 16) throw std::runtime_error("only 16-bit PCM is supported");
+            w.channels = rd16(body + 2);
+            w.sample_rate = (int)rd32(body + 4);
+            have_fmt = true;
+        } else if (std::memcmp(&b[pos], "data", 4) == 0) {
+            const size_t avail = std::min<size_t>(sz, b.size() - pos - 8);
+            w.pcm.resize(avail / 2);
+            std::memcpy(w.pcm.data(), body, w.pcm.size() * 2);
+        }
+        pos += 8 + sz + (sz & 1);
+    }
+    if (!have_fmt || w.pcm.empty()) throw std::runtime_error("Error while loading \"" + path + "\"");
+    return w;
+}
+
+void write_rows(FILE *out, const float *rows, int n, int width, int first_frame, long double t0, long double dt)
+{
+    for (int f = 0; f < n; ++f) {
+        std::fprintf(out, "| %f |", (double)(t0 + (first_frame + f) * dt));
+        for (int i = 0; i < width; ++i) std::fprintf(out, " %f |", rows[(size_t)width * f + i]);
+        std::fprintf(out, "\n");
+    }
+}
+
+void process_file(ParamBase &param, const Options &o, const std::string &in, const std::string &out_name,
+                  float sample_rate)
+{
+    Wav w = read_wav(in);
+    if ((float)w.sample_rate != sample_rate)
+        throw std::runtime_error("File \"" + in + "\" has incorrect sample rate");
+    // mono: first channel (the reference reads one short per frame into a mono-sized buffer)
+    std::vector<int16_t> mono(w.pcm.size() / w.channels);
+    for (size_t i = 0; i < mono.size(); ++i) mono[i] = w.pcm[i * w.channels];
+
+    const int limit = param.get_input_buffer_size();
+    const int width = param.get_output_data_width();
+    const int rows_cap = std::max(param.estimated_window_count(limit), 0) + 64;
+    std::vector<float> rows((size_t)rows_cap * width);
+    const long double dt = o.shift_ms / 1000.0L, t0 = 0.5L * o.window_ms / 1000.0L;
+
+    std::vector<std::pair<float, FILE *>> outs;
+    int idx = 0;
+    for (float a = o.alpha_min; a <= o.alpha_max; a = o.alpha_min + (++idx) * o.alpha_step) {
+        std::string name = out_name;
+        if (o.alpha_max - o.alpha_min >= o.alpha_step) name += "." + std::to_string(a);
+        FILE *fo = std::fopen(name.c_str(), "w");
+        if (!fo) throw std::runtime_error("Can't create output file: " + name);
+        outs.emplace_back(a, fo);
+    }
+    size_t pos = 0;
+    int total = 0;
+    while (pos < mono.size()) {
+        const int n_in = (int)std::min<size_t>(mono.size() - pos, (size_t)limit);
+        const int n = param.set_input(mono.data() + pos, n_in);
+        for (auto &oa : outs) {
+            param.set_alpha(oa.first);
+            param.apply();
+            param.get_output_data(rows.data(), n);
+            write_rows(oa.second, rows.data(), n, width, total, t0, dt);
+        }
+        total += n;
+        pos += n_in;
+    }
+    const int n = param.flush();
+    if (n > 0)
+        for (auto &oa : outs) {
+            param.set_alpha(oa.first);
+            param.apply();
+            param.get_output_data(rows.data(), n);
+            write_rows(oa.second, rows.data(), n, width, total, t0, dt);
+        }
+    total += n;
+    for (auto &oa : outs) std::fclose(oa.second);
+    std::printf("%s: %d frames x %d\n", in.c_str(), total, width);
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    Options o;
+    std::vector<std::string> files;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> const char * {
+            if (i + 1 >= argc) {
+                std::fprintf(stderr, "missing value for %s\n", a.c_str());
+                std::exit(2);
+            }
+            return argv[++i];
+        };
+        if (a == "--window-size") o.window_ms = (float)std::atof(val());
+        else if (a == "--shift") o.shift_ms = (float)std::atof(val());
+        else if (a == "--banks") o.banks = std::atoi(val());
+        else if (a == "--ceps") o.ceps = std::atoi(val());
+        else if (a == "--c0") o.c0 = std::atoi(val()) != 0;
+        else if (a == "--norm") o.norm = std::atoi(val());
+        else if (a == "--dyn") o.dyn = std::atoi(val());
+        else if (a == "--l1") o.l1 = std::atoi(val());
+        else if (a == "--l2") o.l2 = std::atoi(val());
+        else if (a == "--low-freq") o.low = (float)std::atof(val());
+        else if (a == "--high-freq") o.high = (float)std::atof(val());
+        else if (a == "--lift-coef") o.lift = (float)std::atof(val());
+        else if (a == "--norm-after-dyn") o.norm_after_dyn = std::atoi(val()) != 0;
+        else if (a == "--alpha") o.alpha_min = o.alpha_max = (float)std::atof(val());
+        else if (a == "--alpha-min") o.alpha_min = (float)std::atof(val());
+        else if (a == "--alpha-max") o.alpha_max = (float)std::atof(val());
+        else if (a == "--alpha-step") o.alpha_step = (float)std::atof(val());
+        else if (a == "--sample-limit") o.sample_limit = std::atoi(val());
+        else if (a == "--dev") o.device = std::atoi(val());
+        else if (a == "--bug-compat") o.bug_compat = std::atoi(val()) != 0;
+        else if (a == "--help") {
+            std::printf("afet_hip [--window-size ms] [--shift ms] [--banks n] [--ceps n] [--c0 0|1] [--norm 0..3]\n"
+                        "         [--dyn 0..2] [--l1 n] [--l2 n] [--low-freq hz] [--high-freq hz] [--lift-coef x]\n"
+                        "         [--norm-after-dyn 0|1] [--alpha a | --alpha-min a --alpha-max b --alpha-step s]\n"
+                        "         [--sample-limit n] [--dev n] [--bug-compat 0|1]  in.wav out.txt [...]\n");
+            return 0;
+        } else files.push_back(a);
+    }
+    if (files.empty() || files.size() % 2) {
+        std::fprintf(stderr, "usage: afet_hip [options] in.wav out.txt [in2.wav out2.txt ...]  (--help)\n");
+        return 2;
+    }
+    try {
+        const Wav first = read_wav(files[0]); // sample rate from the first file (ASR_OCL.cpp:342-358)
+        const float sr = (float)first.sample_rate;
+        const long W = (long)(sr * o.window_ms * 1e-3), S = (long)(sr * o.shift_ms * 1e-3);
+        if (o.high <= 0) o.high = sr / 2;
+        MfccHip param(o.sample_limit, (int)W, (int)S, o.banks, sr, o.low, o.high, o.ceps, o.c0, o.lift,
+                      (Normalizer::norm_t)o.norm, (ParamBase::dyn_t)o.dyn, o.l1, o.l2, o.norm_after_dyn, o.device,
+                      o.bug_compat);
+        std::vector<float> window((size_t)W);
+        for (long i = 0; i < W; ++i) // ASR_OCL.cpp:149-151
+            window[i] = (float)(0.56f - 0.46f * std::cos((2.0f * M_PI * i) / W)) / 32768.f;
+        param.set_window(window.data());
+        for (size_t i = 0; i < files.size(); i += 2) process_file(param, o, files[i], files[i + 1], sr);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "Exception caught %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

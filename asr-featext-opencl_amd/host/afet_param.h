@@ -1,0 +1,99 @@
+// afet_param.h -- source-compatible mirror of the reference's parameterizer interface, for C++
+// callers that want to swap `new MfccOpenCL(...)` for `new MfccHip(...)` and change nothing else.
+//
+// Mirrors (interface only -- names, argument order and meaning, defaults, error behaviour):
+//     Normalizer::norm_t          normalizer.h:5
+//     class ParamBase             parambase.h:6-33   (+ parambase.cpp:4-19)
+//     class MfccBase              mfccbase.h:6-52    (+ mfccbase.cpp:3-43)
+//     class MfccOpenCL            mfccopencl.h:12-74 -> class MfccHip here
+// All compute happens behind the C ABI of include/mfx.h (libmfcchip.so); nothing in this header
+// or in mfcchip.cpp does arithmetic on samples or features.
+#ifndef AFET_PARAM_H
+#define AFET_PARAM_H
+
+#include <stdexcept>
+
+struct mfx_handle;
+
+namespace Normalizer {
+enum norm_t { NORM_NONE, NORM_CMN, NORM_CVN, NORM_MINMAX };
+}
+
+// Abstract streaming feature extractor: set_window once, then per file
+//   while (samples) { n = set_input(pcm, cnt); set_alpha(a); apply(); get_output_data(out, n); }
+//   n = flush(); if (n > 0) { set_alpha(a); apply(); get_output_data(out, n); }
+// exactly as the reference driver does (ASR_OCL.cpp:152-301).
+class ParamBase {
+public:
+    enum dyn_t { DYN_NONE, DYN_DELTA, DYN_ACC };
+
+    ParamBase(int input_buffer_size, int window_size, int shift, Normalizer::norm_t norm, dyn_t dyn);
+    virtual ~ParamBase() {}
+
+    // largest block set_input accepts: whole frames that fit in the requested size (parambase.cpp:12-13)
+    int get_input_buffer_size() const { return m_input_buffer_size; }
+    // floor(float(samples - (W - S)) / S), float32 arithmetic as the reference (parambase.cpp:16-19)
+    int estimated_window_count(int samples) const;
+    virtual void set_alpha(float alpha) { m_alpha = alpha; }
+
+    virtual void set_window(const float *window) = 0;
+    virtual int set_input(const short *data, int samples) = 0;
+    virtual int flush() = 0;
+    virtual void apply() = 0;
+    virtual int get_output_data_width() const = 0;
+    virtual void get_output_data(float *data_out, int window_count) = 0;
+
+protected:
+    int m_input_buffer_size, m_input_window_limit, m_window_size, m_shift;
+    float m_alpha;
+    Normalizer::norm_t m_norm;
+    dyn_t m_dyn;
+    bool m_last_block;
+};
+
+class MfccBase : public ParamBase {
+public:
+    MfccBase(int input_buffer_size, int window_size, int shift, int num_banks, float sample_rate, float low_freq,
+             float high_freq, int ceps_len, bool want_c0, float lift_coef,
+             Normalizer::norm_t norm = Normalizer::NORM_NONE, dyn_t dyn = DYN_NONE, int delta_l1 = 1,
+             int delta_l2 = 1, bool norm_after_dyn = true);
+    virtual ~MfccBase() {}
+
+    int get_output_data_width() const override;
+
+protected:
+    int m_num_banks, m_ceps_len, m_dct_len, m_delta_l1, m_delta_l2;
+    float m_sample_rate, m_low_freq, m_high_freq, m_lift_coef;
+    bool m_want_c0, m_norm_after_dyn;
+};
+
+// The MI355X back end.  `hip_device` takes the place of MfccOpenCL's trailing cl_device_id
+// (mfccopencl.h:60).  Errors surface as std::runtime_error with the reference's messages.
+class MfccHip : public MfccBase {
+public:
+    MfccHip(int input_buffer_size, int window_size, int shift, int num_banks, float sample_rate, float low_freq,
+            float high_freq, int ceps_len, bool want_c0, float lift_coef,
+            Normalizer::norm_t norm = Normalizer::NORM_NONE, dyn_t dyn = DYN_NONE, int delta_l1 = 1,
+            int delta_l2 = 1, bool norm_after_dyn = true, int hip_device = 0, bool bug_compat = true);
+    ~MfccHip() override;
+    MfccHip(const MfccHip &) = delete;
+    MfccHip &operator=(const MfccHip &) = delete;
+
+    void set_alpha(float alpha) override;
+    void set_window(const float *window) override;
+    int set_input(const short *data, int samples) override;
+    int flush() override;
+    void apply() override;
+    void get_output_data(float *data_out, int window_count) override;
+
+    // upper bound on the rows one set_input()/flush() can deliver (the reference's own bound,
+    // estimated_window_count(get_input_buffer_size()), can be exceeded: SURVEY B6)
+    int max_frames_out() const;
+    mfx_handle *handle() const { return m_handle; }
+
+private:
+    void check(int status) const;
+    mfx_handle *m_handle;
+};
+
+#endif // AFET_PARAM_H

@@ -387,3 +387,27 @@ def test_c2_full_size_properties(pkg, orc):
     for u in (0, 3, 421, 640):
         want = orc.run_utterance(cfg, pcm[u].cpu().numpy(), w, bug_compat=False)
         assert_close(out[rows[u]:rows[u] + 998].cpu().numpy(), want, "C2 utt %d" % u, groups=3)
+
+
+# ---------------------------------------------------------------------------------------------
+# the C++ mirror (class MfccHip : MfccBase) and the afet-style driver built on it
+# ---------------------------------------------------------------------------------------------
+
+def test_cpp_driver_text_output(orc, a0001, tmp_path):
+    """asr-featext-opencl_amd/host/afet_hip: the reference's per-file loop (ASR_OCL.cpp:163-321) in
+    C++ over MfccHip; its text rows ("| time | v | v | ...", %f) must match the oracle."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "asr-featext-opencl_amd", "host", "afet_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    out = tmp_path / "a0001.txt"
+    subprocess.check_call([exe, "--banks", "26", "--ceps", "13", "--c0", "0", "--norm", "0", "--dyn", "2", "--l1", "3",
+                           "--l2", "3", "--sample-limit", "32000", os.path.join(GOLDEN, "a0001.wav"), str(out)])
+    rows = [[float(v) for v in line.strip().strip("|").split("|")] for line in open(out)]
+    got = np.array(rows, dtype=np.float64)
+    assert got.shape == (711, 40)
+    want = orc.run_utterance(orc.make_config(32000, num_banks=26, ceps_len=13), a0001)
+    # column 0 is the frame time: 0.5*window + t*shift (ASR_OCL.cpp:224-225,254)
+    np.testing.assert_allclose(got[:, 0], 0.0125 + 0.01 * np.arange(711), atol=1e-6)
+    assert np.abs(got[:, 1:] - want).max() <= 1e-4 * np.abs(want).max() + 1e-6   # + %f quantisation
