@@ -57,10 +57,36 @@ def synth_pcm_torch(torch, n_utt, utt_samples, sr, seed, device):
     return pcm
 
 
+def host_cpu_share():
+    """Threads this process may really use: the cgroup CPU quota when there is one (a 1-GPU box
+    exposes all host CPUs in the affinity mask but grants a share of them), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(round(int(txt[0]) / float(txt[1])))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(round(q / float(per)))))
+            break
+        except Exception:
+            continue
+    env = os.environ.get("MFX_CPU_THREADS")
+    if env:
+        n = max(1, int(env))
+    elif n > 64:
+        n = 16  # no quota visible on a many-core host: a 1-GPU box's documented CPU share
+    return n
+
+
 def cpu_baseline(orc, wl, pcm_host, window, budget_s=12.0):
     """Oracle (kind "port") timed on this host's cores over a bounded sample of the same workload."""
     import ctypes
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cpu_share()
     # a -march=native build of the same source if the compiler is here; else the portable one
     libpath = None
     try:
@@ -91,8 +117,8 @@ def cpu_baseline(orc, wl, pcm_host, window, budget_s=12.0):
     r1, dt1, f1 = run(n1, 1, 1)
     # all host threads: repeat the resident sample until ~budget seconds of work
     n_all = n_avail
-    est = r1 * cores * 0.5
-    reps = int(max(1, (budget_s * 0.75) * est / (fpu * n_all)))
+    probe_rate, _, _ = run(n_all, cores, 1)        # short probe so that the timed sample fits the budget
+    reps = int(max(1, (budget_s * 0.75) * probe_rate / (fpu * n_all)))
     rall, dtall, fall = run(n_all, cores, reps)
     return {
         "value": rall, "unit": "frames/s", "cores": cores, "kind": "port",

@@ -26,5 +26,17 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
         agg[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 json.dump(res, open(out + "/pmc_summary.json", "w"), indent=1, sort_keys=True)
+# HBM traffic of the dominant kernel per launch.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
+# FETCH_SIZE reports half of the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM;
+# confirmed for this kernel's 4-byte-per-lane loads by tools/ubench/fetch_calib.hip: 1 GiB read ->
+# 524 299 KiB), WRITE_SIZE is exact at 32-byte sector granularity (same calibration).
+k = res.get("k_front512") or res.get("k_front_generic") or {}
+if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+    traffic = {"kernel": "k_front512" if "k_front512" in res else "k_front_generic", "workload": "C2",
+               "fetch_size_kib_raw": k["FETCH_SIZE"], "write_size_kib": k["WRITE_SIZE"],
+               "hbm_read_bytes_per_launch": 2 * 1024 * k["FETCH_SIZE"], "hbm_write_bytes_per_launch": 1024 * k["WRITE_SIZE"],
+               "hbm_bytes_per_launch": 2 * 1024 * k["FETCH_SIZE"] + 1024 * k["WRITE_SIZE"],
+               "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), WRITE_SIZE x1"}
+    json.dump(traffic, open(out + "/traffic.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
 PY
