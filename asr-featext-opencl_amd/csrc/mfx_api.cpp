@@ -26,7 +26,7 @@ const char *kMsgWindow = "Can't process data, window count is too small";
 const char *kMsgProcessed = "Processed samples <= 0, this should never happen";
 const char *kMsgHigh = "Window count too high";
 
-constexpr int kChunkFrames = 64; // frames per work item of the front-end kernels
+constexpr int kChunkFrames = 16; // frames per work item of the front-end kernels
 
 template <class T>
 struct DevBuf {
@@ -71,7 +71,6 @@ struct mfx_handle {
     DevBuf<float> d_window, d_winpair, d_twid_pass, d_twid_half, d_twid_split, d_mel_w, d_dct;
     DevBuf<int32_t> d_mel_beg;
     // 512-point kernel: per-lane mel plan + transposed DCT matrix
-    DevBuf<int32_t> d_work_counter;
     DevBuf<float> d_mel_lane_w, d_dct_t, d_dct_lane_w;
     int dct_lane_stride = 0;
     DevBuf<int32_t> d_mel_lane_start, d_mel_lane_fid;
@@ -102,7 +101,7 @@ struct mfx_handle {
     std::vector<Chunk> h_chunks;
     DevBuf<Chunk> d_chunks;
     DevBuf<Segment> d_segs;
-    DevBuf<float> d_stats_batch, d_spec_slab;
+    DevBuf<float> d_stats_batch, d_spec_slab, d_static16; // d_static16: compact [rows][16] statics between front end and delta
     int tiles_max = 0;
     bool batch_aligned = true;
 
@@ -201,7 +200,6 @@ void fill_front(const mfx_handle *h, FrontParams &p)
     p.mel_rounds = h->plan.rounds;
     p.mel_row_stride = h->plan.row_stride;
     for (int i = 0; i < 8; ++i) p.mel_L[i] = h->plan.L[i];
-    p.work_counter = h->d_work_counter.p;
     p.dct_lane_w = h->d_dct_lane_w.p;
     p.dct_mode = (h->ceps > 0 && h->cols <= 16 && h->d_dct_lane_w.p) ? 1 : 0;
     p.dct_stride = p.dct_mode == 1 ? h->dct_lane_stride : h->dct_stride;
@@ -316,7 +314,6 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_mel_lane_w.release();
     h->d_dct_t.release();
     h->d_dct_lane_w.release();
-    h->d_work_counter.release();
     h->d_mel_lane_start.release();
     h->d_mel_lane_fid.release();
     h->d_carry[0].release();
@@ -330,6 +327,7 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_segs.release();
     h->d_stats_batch.release();
     h->d_spec_slab.release();
+    h->d_static16.release();
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -401,7 +399,6 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(MFX_ERR_DEVICE);
     h->own_stream = true;
 
-    if (h->d_work_counter.alloc(4) != hipSuccess) return bail(MFX_ERR_DEVICE);
     // ---- constant tables
     {
         std::vector<float> tw;
@@ -755,7 +752,7 @@ extern "C" int mfx_apply(mfx_handle *h)
     dp.cols = h->cols;
     dp.l1 = h->l1;
     dp.l2 = h->l2;
-    dp.tiles_per_seg_max = (wc + 63) / 64;
+    dp.tiles_per_seg_max = (wc + 127) / 128;
     dp.inline_seg = 1;
     sg.src_row0 = 0;
     sg.out_row0 = 0;
@@ -856,7 +853,7 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
         s.lo = 0;
         s.hi = (int32_t)std::max<int64_t>(T - 1, 0);
         s.static_off = 0;
-        tiles_max = std::max<int>(tiles_max, (int)((T + 63) / 64));
+        tiles_max = std::max<int>(tiles_max, (int)((T + 127) / 128));
         row += T;
     }
     h->total_rows = row;
@@ -866,6 +863,9 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
     HIP_TRY(h, upload(h->d_chunks, h->h_chunks));
     HIP_TRY(h, upload(h->d_segs, segs));
     if (h->cfg.norm != MFX_NORM_NONE) HIP_TRY(h, h->d_stats_batch.alloc((size_t)n_utt * 3 * 2 * h->cols));
+    // scratch for the compact statics (allocated here so that mfx_batch_run_device itself never allocates)
+    if (h->fast512 && h->l1 > 0 && h->cols <= 16 && h->d_static16.n < (size_t)row * 16)
+        HIP_TRY(h, h->d_static16.alloc((size_t)row * 16));
     return MFX_OK;
 }
 
@@ -892,6 +892,16 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
     p.feat = d_out;
     p.feat_pitch = h->width;
 
+    // With deltas on, the front end writes its statics as compact 64-byte rows into a scratch buffer
+    // and the delta kernel emits whole [static | d | dd] rows: every HBM write is then a full line
+    // (13-float row pieces at a 156-byte pitch cost 1.5x their size in 32-byte sectors).
+    const bool norm_before = h->cfg.norm != MFX_NORM_NONE && !h->cfg.norm_after_dyn;
+    const bool via_scratch = h->fast512 && h->fused_ok && h->l1 > 0 && h->cols <= 16 && p.dct_mode == 1 && !norm_before;
+    if (via_scratch) {
+        if (h->d_static16.n < (size_t)h->total_rows * 16) HIP_TRY(h, h->d_static16.alloc((size_t)h->total_rows * 16));
+        p.feat = h->d_static16.p;
+        p.feat_pitch = 16;
+    }
     if (h->fast512 && h->fused_ok) {
         p.spec = h->d_spec.p; // unused by the fused kernel; a -DMFX_STAMPS dev build drops its cycle sums here
         ProfScope ps(h);
@@ -951,8 +961,8 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
     if (h->l1 > 0) {
         DeltaParams dp;
         std::memset(&dp, 0, sizeof(dp));
-        dp.src = d_out;
-        dp.src_pitch = h->width;
+        dp.src = via_scratch ? h->d_static16.p : d_out;
+        dp.src_pitch = via_scratch ? 16 : h->width;
         dp.out = d_out;
         dp.out_pitch = h->width;
         dp.segs = h->d_segs.p;

@@ -64,7 +64,6 @@ struct FrontParams {
     const int32_t *mel_lane_start;// [mel_rounds][16] first bin of the lane's filter in that round
     const int32_t *mel_lane_fid;  // [mel_rounds][16] filter index or -1
     const float *dct_t;           // [cols][dct_stride] transposed DCT matrix, rows zero padded to nb_pad
-    int32_t *work_counter;        // zeroed before every launch: next chunk index (dynamic work distribution)
     const float *dct_lane_w;      // [16][dct_stride] per-lane DCT rows, one 16-float group per round (dct_mode 1)
     int32_t dct_mode;             // 0: DCT from the LDS mel scratch; 1: fused into the mel rounds + DPP reduce (cols <= 16)
     int32_t mel_rounds, mel_row_stride, dct_stride, nb_pad;

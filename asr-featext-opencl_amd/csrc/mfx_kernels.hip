@@ -277,49 +277,64 @@ __global__ void __launch_bounds__(512, 4) k_front512(FrontParams p)
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt0)::"memory");
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
-    // Chunks are handed out dynamically (one relaxed device-scope atomic per 64 frames, fetched one
-    // chunk ahead): waves that share a SIMD with slower partners would otherwise finish up to 40 %
-    // apart under a static split.
-    // The first chunk of every wave is its own index (no atomic burst at start-up); the shared
-    // counter, preset to the number of waves in the grid, hands out the rest.
-    int c = blockIdx.x * 8 + wave, c_next = 0;
-    for (; c < p.n_chunks; c = c_next) {
-        if (lane == 0) c_next = __hip_atomic_fetch_add(p.work_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // wave-uniform chunk descriptor -> scalar registers
-        const Chunk *chp = p.chunks + c;
+    // Work distribution.  Chunks (<= 16 consecutive frames of one utterance) are dealt round-robin to
+    // the waves of the grid (wave w takes chunks w, w + W, w + 2W, ...).  A shared atomic counter was
+    // tried and lost: one word serves ~88 fetch-adds per microsecond, which bounds the kernel once
+    // chunks are small enough to even out the tail.  The chunk walk is software pipelined so that a
+    // chunk boundary costs no memory latency: the next chunk's descriptor is already in scalar
+    // registers and the last iteration of a chunk prefetches the first frames of the next one.
+    struct ChunkCtx {
+        int64_t out_row;
+        int n_live, odd0;
+        __amdgpu_buffer_rsrc_t rsrc;
+    };
+    auto make_ctx = [&](int c) -> ChunkCtx {
+        ChunkCtx x;
+        const bool valid = c < p.n_chunks;
+        const Chunk *chp = p.chunks + (valid ? c : 0);
         const int64_t pcm_off = chp->pcm_off;
-        const int64_t out_row = chp->out_row;
-        const int n_frames = chp->n_frames;
-        int64_t rows_left = p.row_limit - out_row;
-        const int n_live = (int)(rows_left < n_frames ? (rows_left < 0 ? 0 : rows_left) : n_frames);
+        x.out_row = chp->out_row;
+        const int n_frames = valid ? chp->n_frames : 0;
+        const int64_t rows_left = p.row_limit - x.out_row;
+        x.n_live = (int)(rows_left < n_frames ? (rows_left < 0 ? 0 : rows_left) : n_frames);
         // buffer descriptor over [chunk start, end of PCM): out-of-range lanes read 0
         const int64_t base_s = ALIGNED ? pcm_off : (pcm_off & ~(int64_t)1);
-        const int odd0 = ALIGNED ? 0 : (int)(pcm_off & 1);
-        int64_t bytes_left = (p.pcm_total - base_s) * 2;
+        x.odd0 = ALIGNED ? 0 : (int)(pcm_off & 1);
+        int64_t bytes_left = valid ? (p.pcm_total - base_s) * 2 : 0;
         if (bytes_left > 0xfffffff0ll) bytes_left = 0xfffffff0ll;
         if (bytes_left < 0) bytes_left = 0;
         const uintptr_t bp = (uintptr_t)(p.pcm + base_s);
         const uint32_t bp_lo = __builtin_amdgcn_readfirstlane((uint32_t)bp);
         const uint32_t bp_hi = __builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32));
         const uint32_t nbytes = __builtin_amdgcn_readfirstlane((uint32_t)bytes_left);
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(((uintptr_t)bp_hi << 32) | bp_lo), 0, nbytes, 0x00020000);
+        x.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(((uintptr_t)bp_hi << 32) | bp_lo), 0, nbytes, 0x00020000);
+        return x;
+    };
+    // byte offset of (frame f, sample pair l) relative to the chunk's descriptor base
+    auto lane_off = [&](const ChunkCtx &x, int f) -> int {
+        const int s = x.odd0 + f * p.shift + 2 * l;
+        return ALIGNED ? s * 2 : (s & ~1) * 2;
+    };
+    const int c_step = gridDim.x * 8;
+    int c_cur = blockIdx.x * 8 + wave;
+    int c_nxt = c_cur + c_step;
+    ChunkCtx ccur = make_ctx(c_cur);
+    ChunkCtx cnxt = make_ctx(c_nxt);
+    PcmRegs<ALIGNED, NM> cur, nxt;
+    pcm_issue<ALIGNED, NM>(cur, ccur.rsrc, lane_off(ccur, slot));
 
-        PcmRegs<ALIGNED, NM> cur, nxt;
-        // sample offset of (frame f, pair l) relative to base_s: odd0 + f*S + 2*l
-        auto lane_off = [&](int f) -> int {
-            const int s = odd0 + f * p.shift + 2 * l;  // first sample of the lane's pair
-            return ALIGNED ? s * 2 : (s & ~1) * 2;
-        };
-        pcm_issue<ALIGNED, NM>(cur, rsrc, lane_off(slot));
-
+    while (c_cur < p.n_chunks) {
+        const int64_t out_row = ccur.out_row;
+        const int n_live = ccur.n_live;
+        const int odd0 = ccur.odd0;
         for (int f0 = 0; f0 < n_live; f0 += 4) {
             const int f = f0 + slot;
             const bool live = f < n_live;
-            // Prefetch the next iteration unconditionally: a conditional issue would make the number of
-            // loads in flight path-dependent and force the compiler to wait for vmcnt(0) here.  Past the
-            // chunk's last frame this reads the following frames (or 0 beyond the array): harmless.
-            pcm_issue<ALIGNED, NM>(nxt, rsrc, lane_off(f + 4));
+            // Prefetch unconditionally (a conditional issue would make the number of loads in flight
+            // path-dependent and force a vmcnt(0) wait here): the next 4 frames of this chunk or, from
+            // the chunk's last iteration, the first 4 frames of the next chunk.
+            const bool last = f0 + 4 >= n_live;
+            pcm_issue<ALIGNED, NM>(nxt, last ? cnxt.rsrc : ccur.rsrc, last ? lane_off(cnxt, slot) : lane_off(ccur, f + 4));
 
             MFX_STAMP(0);
             // ---- framing + window: z[l + 16m] = (w[2n] x[2n], w[2n+1] x[2n+1])
@@ -475,7 +490,8 @@ __global__ void __launch_bounds__(512, 4) k_front512(FrontParams p)
                         }
                     }
                     const float outv = row_reduce16(part, l);
-                    if (live && l < cols) dst[l] = outv;
+                    // pitch 16 = compact static scratch: write whole 64-byte rows (zeros beyond cols)
+                    if (live && (l < cols || p.feat_pitch == 16)) dst[l] = l < cols ? outv : 0.f;
                 } else {
                     float *melbuf = xb + kMelOff;
                     for (int r = 0; r < rounds; ++r) {
@@ -523,9 +539,12 @@ __global__ void __launch_bounds__(512, 4) k_front512(FrontParams p)
             MFX_STAMP(6);
             cur = nxt;
         }
-        // keep the atomic's result in flight until here (an opaque use pins the broadcast below it)
-        asm volatile("" : "+v"(c_next));
-        c_next = __builtin_amdgcn_readfirstlane(c_next);
+        if (n_live <= 0) pcm_issue<ALIGNED, NM>(cur, cnxt.rsrc, lane_off(cnxt, slot)); // empty chunk: nothing was prefetched
+        // rotate the pipeline: next -> current, load the descriptor after next
+        c_cur = c_nxt;
+        ccur = cnxt;
+        c_nxt += c_step;
+        cnxt = make_ctx(c_nxt);
     }
 #ifdef MFX_STAMPS
     if (lane == 0 && p.spec) {
@@ -657,8 +676,11 @@ __global__ void __launch_bounds__(256) k_melcep(MelcepParams p)
 // MfccCpu::do_delta (mfcccpu.cpp:234-263) expressed as a clamped row accessor (Segment).
 // grid = (tiles, segments); one tile = kDeltaRows output rows.
 // ------------------------------------------------------------------------------------------------
-constexpr int kDeltaRows = 64;
+constexpr int kDeltaRows = 128;
 
+// FAST16: cols <= 16 -> a row is 16 consecutive work items (no integer division by a run-time
+// column count, 13..16 consecutive floats per row piece); otherwise the generic index split.
+template <bool FAST16>
 __global__ void __launch_bounds__(256) k_delta(DeltaParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -667,48 +689,85 @@ __global__ void __launch_bounds__(256) k_delta(DeltaParams p)
     if (r0 >= sg.n_out) return;
     const int rows = min(kDeltaRows, sg.n_out - r0);
     const int cols = p.cols, l1 = p.l1, l2 = p.l2, D = l1 + l2;
+    const int cw = FAST16 ? 16 : cols; // row width in work items and in LDS
     const int tid = threadIdx.x;
-    float *s_pad = smem;                               // [rows + 2D][cols]
-    float *s_d = smem + (kDeltaRows + 2 * D) * cols;   // [rows + 2*l2][cols]
+    float *s_pad = smem;                             // [rows + 2D][cw]
+    float *s_d = smem + (kDeltaRows + 2 * D) * cw;   // [rows + 2*l2][cw]
+    auto split = [&](int i, int &rr, int &c) {
+        if (FAST16) {
+            rr = i >> 4;
+            c = i & 15;
+        } else {
+            rr = i / cols;
+            c = i - rr * cols;
+        }
+    };
 
     if (l1 > 0) {
-        const int n_pad = (rows + 2 * D) * cols;
+        const int n_pad = (rows + 2 * D) * cw;
         for (int i = tid; i < n_pad; i += 256) {
-            const int rr = i / cols, c = i - rr * cols;
+            int rr, c;
+            split(i, rr, c);
             int sr = r0 + rr + sg.shift;
             sr = max(sg.lo, min(sg.hi, sr));
-            s_pad[i] = p.src[(sg.src_row0 + sr) * (int64_t)p.src_pitch + c];
+            s_pad[i] = (c < cols) ? p.src[(sg.src_row0 + sr) * (int64_t)p.src_pitch + c] : 0.f;
         }
         __syncthreads();
         float den = 0.f;
         for (int l = 1; l <= l1; ++l) den += (float)(l * l);
-        const int n_d = (rows + 2 * l2) * cols;
+        const int n_d = (rows + 2 * l2) * cw;
         for (int i = tid; i < n_d; i += 256) {
-            const int rr = i / cols, c = i - rr * cols;
             float num = 0.f;
-            for (int l = 1; l <= l1; ++l)
-                num += (float)l * (s_pad[(rr + l1 + l) * cols + c] - s_pad[(rr + l1 - l) * cols + c]);
+            for (int l = 1; l <= l1; ++l) num += (float)l * (s_pad[i + (l1 + l) * cw] - s_pad[i + (l1 - l) * cw]);
             s_d[i] = num / (2 * den);
         }
         __syncthreads();
     }
-    float den2 = 0.f;
-    for (int l = 1; l <= l2; ++l) den2 += (float)(l * l);
-    const bool in_place = (p.src == p.out) && (sg.src_row0 + sg.static_off == sg.out_row0) && (p.src_pitch == p.out_pitch);
-    const int n_o = rows * cols;
+    float *s_dd = s_d + (kDeltaRows + 2 * l2) * cw;  // [rows][cw]
+    if (l2 > 0) {
+        float den2 = 0.f;
+        for (int l = 1; l <= l2; ++l) den2 += (float)(l * l);
+        const int n_dd = rows * cw;
+        for (int i = tid; i < n_dd; i += 256) {
+            float num = 0.f;
+            for (int l = 1; l <= l2; ++l) num += (float)l * (s_d[i + (l2 + l) * cw] - s_d[i + (l2 - l) * cw]);
+            s_dd[i] = num / (2 * den2);
+        }
+        __syncthreads();
+    }
+    // The tile's output rows are one contiguous block of rows * width floats: write it with
+    // consecutive threads on consecutive addresses (whole cache lines), statics included.
+    const int width = p.out_pitch == cols * (l2 > 0 ? 3 : l1 > 0 ? 2 : 1) ? p.out_pitch : 0;
+    const int stat_row = sg.static_off - sg.shift; // row of s_pad that holds the static part of output row 0
+    if (width > 0 && l1 > 0) {
+        float *obase = p.out + (sg.out_row0 + r0) * (int64_t)p.out_pitch;
+        const uint32_t magic = 0xffffffffu / (uint32_t)width + 1; // floor(i / width) for i < 2^16
+        const int n_o = rows * width;
+        for (int i = tid; i < n_o; i += 256) {
+            const int rr = (int)__umulhi((uint32_t)i, magic);
+            const int cc = i - rr * width;
+            float v;
+            if (cc < cols)
+                v = s_pad[(rr + stat_row) * cw + cc];
+            else if (cc < 2 * cols)
+                v = s_d[(rr + l2) * cw + cc - cols];
+            else
+                v = s_dd[rr * cw + cc - 2 * cols];
+            obase[i] = v;
+        }
+        return;
+    }
+    // generic fallback (row pitch wider than the feature row, or statics only)
+    const int n_o = rows * cw;
     for (int i = tid; i < n_o; i += 256) {
-        const int rr = i / cols, c = i - rr * cols;
+        int rr, c;
+        split(i, rr, c);
+        if (c >= cols) continue;
         float *orow = p.out + (sg.out_row0 + r0 + rr) * (int64_t)p.out_pitch;
-        if (!in_place)
-            orow[c] = p.src[(sg.src_row0 + r0 + rr + sg.static_off) * (int64_t)p.src_pitch + c];
+        orow[c] = p.src[(sg.src_row0 + r0 + rr + sg.static_off) * (int64_t)p.src_pitch + c];
         if (l1 > 0) {
-            orow[cols + c] = s_d[(rr + l2) * cols + c];
-            if (l2 > 0) {
-                float num = 0.f;
-                for (int l = 1; l <= l2; ++l)
-                    num += (float)l * (s_d[(rr + l2 + l) * cols + c] - s_d[(rr + l2 - l) * cols + c]);
-                orow[2 * cols + c] = num / (2 * den2);
-            }
+            orow[cols + c] = s_d[i + l2 * cw];
+            if (l2 > 0) orow[2 * cols + c] = s_dd[i];
         }
     }
 }
@@ -821,9 +880,6 @@ hipError_t launch512(const FrontParams &p, hipStream_t stream)
     const int cap = num_cus() * 2;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    // work counter := number of waves in the grid (hipMemsetD32Async writes one 32-bit word)
-    hipError_t e0 = hipMemsetD32Async((hipDeviceptr_t)p.work_counter, blocks * 8, 1, stream);
-    if (e0 != hipSuccess) return e0;
     hipLaunchKernelGGL((k_front512<A, S, NM>), dim3(blocks), dim3(512), lds, stream, p);
     return hipGetLastError();
 }
@@ -891,9 +947,12 @@ hipError_t launch_delta(const DeltaParams &p, hipStream_t stream)
 {
     if (p.n_segs <= 0 || p.tiles_per_seg_max <= 0) return hipSuccess;
     const int D = p.l1 + p.l2;
-    const size_t lds = (size_t)((kDeltaRows + 2 * D) + (kDeltaRows + 2 * p.l2)) * p.cols * sizeof(float);
+    const bool fast16 = p.cols <= 16;
+    const int cw = fast16 ? 16 : p.cols;
+    const size_t lds = (size_t)((kDeltaRows + 2 * D) + (kDeltaRows + 2 * p.l2) + kDeltaRows) * cw * sizeof(float);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_delta, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fast16 ? (const void *)k_delta<true> : (const void *)k_delta<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     // grid.y is limited to 65535: split the segment list
@@ -901,7 +960,10 @@ hipError_t launch_delta(const DeltaParams &p, hipStream_t stream)
         DeltaParams q = p;
         q.segs = p.segs + s0;
         q.n_segs = (p.n_segs - s0) < 65535 ? (p.n_segs - s0) : 65535;
-        hipLaunchKernelGGL(k_delta, dim3(p.tiles_per_seg_max, q.n_segs), dim3(256), lds, stream, q);
+        if (fast16)
+            hipLaunchKernelGGL(k_delta<true>, dim3(p.tiles_per_seg_max, q.n_segs), dim3(256), lds, stream, q);
+        else
+            hipLaunchKernelGGL(k_delta<false>, dim3(p.tiles_per_seg_max, q.n_segs), dim3(256), lds, stream, q);
     }
     return hipGetLastError();
 }
