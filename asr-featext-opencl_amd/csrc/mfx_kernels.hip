@@ -115,7 +115,7 @@ __device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int
 
 // ------------------------------------------------------------------------------------------------
 // 512-point front end.  One wave owns 4 frames per iteration, 16 lanes per frame; a 512-thread
-// block is 8 such waves sharing one set of LDS tables, two blocks per CU.
+// block is 16 such waves sharing one set of LDS tables and one work counter, one block per CU.
 //
 //   real 512-point DFT of a frame = complex 256-point DFT of z[n] = x[2n] + i x[2n+1] + real split
 //   256 = 16 x 16:   lane l  : 16-point DFT over m of z[l + 16m]        (registers)
@@ -135,6 +135,8 @@ __device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int
 // 0) one iteration ahead of its use.
 // ------------------------------------------------------------------------------------------------
 constexpr int kSlot = 512;    // dwords per frame slot
+constexpr int kWaves = 16;    // waves per block of the 512-point kernel (one block per CU)
+constexpr int kThreads = kWaves * 64;
 constexpr int kMelOff = 304;  // mel scratch offset inside the slot (after 32 + 257 magnitudes)
 
 // y[l] = x[(16 - l) & 15] inside every row of 16 lanes: mirror, then rotate right by one
@@ -229,7 +231,7 @@ __device__ __forceinline__ void pcm_issue(PcmRegs<ALIGNED, NM> &r, __amdgpu_buff
 #endif
 
 template <bool ALIGNED, bool TO_SPEC, int NM>
-__global__ void __launch_bounds__(512, 4) k_front512(FrontParams p)
+__global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -250,21 +252,23 @@ __global__ void __launch_bounds__(512, 4) k_front512(FrontParams p)
     const int dct_floats = p.dct ? (p.dct_mode == 1 ? 16 : cols) * DS : 0;
     float *s_wave = s_dct + dct_floats + wave * (4 * kSlot);
     float *xb = s_wave + slot * kSlot;
+    int *s_ctr = (int *)(s_dct + dct_floats + kWaves * (4 * kSlot)); // block-local work counter
+    if (tid == 0) *s_ctr = 0;
 
-    for (int i = tid; i < 256; i += 512) {
+    for (int i = tid; i < 256; i += kThreads) {
         // HBM tables are [lane][m]; the LDS copies are [m][lane]: one instruction reads one row,
         // 16 consecutive 8-byte words (the 4 frames of a wave read the same words: broadcast)
         s_win[i] = ((const float2 *)p.winpair)[(i & 15) * 16 + (i >> 4)];
         s_tw[i] = ((const float2 *)p.twid_pass)[(i & 15) * 16 + (i >> 4)];
     }
-    for (int i = tid; i < 257; i += 512) s_split[i] = ((const float2 *)p.twid_split)[i];
+    for (int i = tid; i < 257; i += kThreads) s_split[i] = ((const float2 *)p.twid_split)[i];
     if (!TO_SPEC) {
-        for (int i = tid; i < 16 * RS; i += 512) s_melw[i] = p.mel_lane_w[i];
-        for (int i = tid; i < 16 * rounds; i += 512) {
+        for (int i = tid; i < 16 * RS; i += kThreads) s_melw[i] = p.mel_lane_w[i];
+        for (int i = tid; i < 16 * rounds; i += kThreads) {
             s_mstart[i] = p.mel_lane_start[i];
             s_mfid[i] = p.mel_lane_fid[i];
         }
-        for (int i = tid; i < dct_floats; i += 512) s_dct[i] = (p.dct_mode == 1 ? p.dct_lane_w : p.dct_t)[i];
+        for (int i = tid; i < dct_floats; i += kThreads) s_dct[i] = (p.dct_mode == 1 ? p.dct_lane_w : p.dct_t)[i];
     }
     // the slots are read (times zero weights) before every word has been written once: make them finite
     for (int i = lane; i < 4 * kSlot; i += 64) s_wave[i] = 0.f;
@@ -315,9 +319,21 @@ __global__ void __launch_bounds__(512, 4) k_front512(FrontParams p)
         const int s = x.odd0 + f * p.shift + 2 * l;
         return ALIGNED ? s * 2 : (s & ~1) * 2;
     };
-    const int c_step = gridDim.x * 8;
-    int c_cur = blockIdx.x * 8 + wave;
-    int c_nxt = c_cur + c_step;
+    // Block b owns chunks b, b + B, b + 2B, ...; its waves draw from that list through a counter in
+    // LDS (a ds_add_rtn costs ~100 cycles and contends with the block's other waves only), so waves that the
+    // SIMD arbiter favours simply take more chunks instead of finishing early and idling the CU.
+    auto next_index = [&]() -> int {
+        int k = 0;
+        if (lane == 0) k = __hip_atomic_fetch_add(s_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return k;
+    };
+    auto chunk_of = [&](int k) -> int {
+        const long long c = (long long)blockIdx.x + (long long)k * gridDim.x;
+        return c < p.n_chunks ? (int)c : p.n_chunks;
+    };
+    int v_a = next_index(), v_b = next_index(), v_nn = next_index();
+    int c_cur = chunk_of(__builtin_amdgcn_readfirstlane(v_a));
+    int c_nxt = chunk_of(__builtin_amdgcn_readfirstlane(v_b));
     ChunkCtx ccur = make_ctx(c_cur);
     ChunkCtx cnxt = make_ctx(c_nxt);
     PcmRegs<ALIGNED, NM> cur, nxt;
@@ -540,15 +556,17 @@ __global__ void __launch_bounds__(512, 4) k_front512(FrontParams p)
             cur = nxt;
         }
         if (n_live <= 0) pcm_issue<ALIGNED, NM>(cur, cnxt.rsrc, lane_off(cnxt, slot)); // empty chunk: nothing was prefetched
-        // rotate the pipeline: next -> current, load the descriptor after next
+        // rotate the pipeline: next -> current, the index drawn a chunk ago -> next, draw another
         c_cur = c_nxt;
         ccur = cnxt;
-        c_nxt += c_step;
+        asm volatile("" : "+v"(v_nn)); // keep the LDS atomic's result in flight until here
+        c_nxt = chunk_of(__builtin_amdgcn_readfirstlane(v_nn));
         cnxt = make_ctx(c_nxt);
+        v_nn = next_index();
     }
 #ifdef MFX_STAMPS
     if (lane == 0 && p.spec) {
-        unsigned long long *o = (unsigned long long *)p.spec + (size_t)(blockIdx.x * 8 + wave) * 8;
+        unsigned long long *o = (unsigned long long *)p.spec + (size_t)(blockIdx.x * kWaves + wave) * 8;
         unsigned long long st_rt1;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1)::"memory");
         st_acc[7] = st_rt1 - st_rt0; // 100 MHz ticks over the same span
@@ -861,26 +879,34 @@ size_t front512_lds_bytes(const FrontParams &p)
     f += (size_t)16 * p.mel_row_stride;                  // per-lane mel weights
     f += (size_t)32 * p.mel_rounds;                      // per-lane bin starts + filter ids
     f += p.dct ? (size_t)(p.dct_mode == 1 ? 16 : p.cols) * p.dct_stride : 0; // DCT table (either layout)
-    f += 8 * 4 * kSlot;                                  // 8 waves x 4 frame slots
+    f += kWaves * 4 * kSlot;                             // 4 frame slots per wave
+    f += 4;                                              // block-local work counter
     return f * sizeof(float);
 }
 
 namespace {
 
 template <bool A, bool S, int NM>
-hipError_t launch512(const FrontParams &p, hipStream_t stream)
+hipError_t launch512(const FrontParams &p_in, hipStream_t stream)
 {
+    FrontParams p = p_in;
+    if (S) { // spectrum only: no mel / DCT tables in LDS
+        p.mel_rounds = 0;
+        p.mel_row_stride = 0;
+        p.dct = nullptr;
+        p.dct_mode = 0;
+    }
     const size_t lds = front512_lds_bytes(p);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)k_front512<A, S, NM>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    int blocks = (p.n_chunks + 7) / 8;
-    const int cap = num_cus() * 2;
+    int blocks = (p.n_chunks + kWaves - 1) / kWaves;
+    const int cap = num_cus() * (32 / kWaves) / 2; // 16 waves per CU
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_front512<A, S, NM>), dim3(blocks), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((k_front512<A, S, NM>), dim3(blocks), dim3(kThreads), lds, stream, p);
     return hipGetLastError();
 }
 

@@ -294,6 +294,19 @@ def test_c5_shape_2048_odd_shift_stereo(pkg, orc):
     assert_close(ms.batch_run_host(inter), want, "C5 stereo downmix", groups=3)
 
 
+@pytest.mark.parametrize("nb,nc,c0", [(40, 20, False), (64, 24, True), (80, 13, False), (128, 40, False)])
+def test_512pt_wide_outputs_and_many_filters(pkg, orc, nb, nc, c0):
+    """512-point front end with more than 16 output columns (DCT from the LDS mel scratch instead of
+    the DPP-fused path) and with many mel rounds / large tables (falls back to spectrum + melcep when
+    the fused kernel's LDS budget is exceeded)."""
+    pcm = synth_utterance(30000, 21)
+    m, cfg, w = make_pair(pkg, orc, 12000, nb=nb, nc=nc, c0=c0, dyn=1, l1=2)
+    want = orc.run_utterance(cfg, pcm, w, bug_compat=False)
+    m.batch_plan([0], [pcm.size])
+    assert_close(m.batch_run_host(pcm), want, "512-pt nb=%d nc=%d batch" % (nb, nc), groups=2)
+    assert_close(m.process_stream(pcm), orc.run_utterance(cfg, pcm, w), "512-pt nb=%d nc=%d stream" % (nb, nc), groups=2)
+
+
 def test_window_8khz_256(pkg, orc):
     pcm = synth_utterance(24000, 13, sr=8000.0)
     m, cfg, w = make_pair(pkg, orc, 8000, W=200, S=80, nb=23, sr=8000.0, nc=12, c0=True)
