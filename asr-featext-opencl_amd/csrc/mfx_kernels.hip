@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
     int c_nxt = chunk_of(__builtin_amdgcn_readfirstlane(v_b));
     ChunkCtx ccur = make_ctx(c_cur);
     ChunkCtx cnxt = make_ctx(c_nxt);
-    PcmRegs<ALIGNED, NM> cur, nxt;
+    PcmRegs<ALIGNED, NM> cur;
     pcm_issue<ALIGNED, NM>(cur, ccur.rsrc, lane_off(ccur, slot));
 
     while (c_cur < p.n_chunks) {
@@ -346,11 +346,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
         for (int f0 = 0; f0 < n_live; f0 += 4) {
             const int f = f0 + slot;
             const bool live = f < n_live;
-            // Prefetch unconditionally (a conditional issue would make the number of loads in flight
-            // path-dependent and force a vmcnt(0) wait here): the next 4 frames of this chunk or, from
-            // the chunk's last iteration, the first 4 frames of the next chunk.
             const bool last = f0 + 4 >= n_live;
-            pcm_issue<ALIGNED, NM>(nxt, last ? cnxt.rsrc : ccur.rsrc, last ? lane_off(cnxt, slot) : lane_off(ccur, f + 4));
 
             MFX_STAMP(0);
             // ---- framing + window: z[l + 16m] = (w[2n] x[2n], w[2n+1] x[2n+1])
@@ -374,6 +370,11 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
                     a[m] = make_float2(0.f, 0.f);
                 }
             }
+
+            // Prefetch into the registers just consumed, unconditionally (a conditional issue would make
+            // the number of loads in flight path-dependent and force a vmcnt(0) wait): the next 4 frames
+            // of this chunk or, from the chunk's last iteration, the first 4 frames of the next chunk.
+            pcm_issue<ALIGNED, NM>(cur, last ? cnxt.rsrc : ccur.rsrc, last ? lane_off(cnxt, slot) : lane_off(ccur, f + 4));
 
             MFX_STAMP(1);
             // ---- pass A + inter-pass twiddle
@@ -444,7 +445,6 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
                     for (int pp = 0; pp < 16; ++pp) acc += mag[pp];
                     float *dstx = p.feat + (out_row + (live ? f : 0)) * (int64_t)p.feat_pitch;
                     if (live && l < cols) dstx[l] = acc;
-                    cur = nxt;
                     continue;
                 }
 #endif
@@ -553,7 +553,6 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
                 wave_sync();
             }
             MFX_STAMP(6);
-            cur = nxt;
         }
         if (n_live <= 0) pcm_issue<ALIGNED, NM>(cur, cnxt.rsrc, lane_off(cnxt, slot)); // empty chunk: nothing was prefetched
         // rotate the pipeline: next -> current, the index drawn a chunk ago -> next, draw another
