@@ -752,7 +752,7 @@ extern "C" int mfx_apply(mfx_handle *h)
     dp.cols = h->cols;
     dp.l1 = h->l1;
     dp.l2 = h->l2;
-    dp.tiles_per_seg_max = (wc + 127) / 128;
+    dp.tiles_per_seg_max = (wc + 63) / 64;
     dp.inline_seg = 1;
     sg.src_row0 = 0;
     sg.out_row0 = 0;
@@ -853,7 +853,7 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
         s.lo = 0;
         s.hi = (int32_t)std::max<int64_t>(T - 1, 0);
         s.static_off = 0;
-        tiles_max = std::max<int>(tiles_max, (int)((T + 127) / 128));
+        tiles_max = std::max<int>(tiles_max, (int)((T + 63) / 64));
         row += T;
     }
     h->total_rows = row;

@@ -693,7 +693,7 @@ __global__ void __launch_bounds__(256) k_melcep(MelcepParams p)
 // MfccCpu::do_delta (mfcccpu.cpp:234-263) expressed as a clamped row accessor (Segment).
 // grid = (tiles, segments); one tile = kDeltaRows output rows.
 // ------------------------------------------------------------------------------------------------
-constexpr int kDeltaRows = 128;
+constexpr int kDeltaRows = 64;
 
 // FAST16: cols <= 16 -> a row is 16 consecutive work items (no integer division by a run-time
 // column count, 13..16 consecutive floats per row piece); otherwise the generic index split.
