@@ -402,7 +402,7 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
     // ---- constant tables
     {
         std::vector<float> tw;
-        build_twiddles(h->W2 / 2, std::max(1, h->W2 / 4), tw); // W_M^k, k < M/2
+        build_twiddles(h->W2 / 2, h->W2 / 2, tw); // W_M^k, k < M (radix-4 stages use k, 2k, 3k)
         if (upload(h->d_twid_half, tw) != hipSuccess) return bail(MFX_ERR_DEVICE);
         std::vector<float> ws;
         build_twiddles(h->W2, h->W2 / 2 + 1, ws); // W_{W2}^k
@@ -585,7 +585,7 @@ int stream_front(mfx_handle *h, int wcnd)
     if (h->fast512)
         HIP_TRY(h, launch_front512(p, /*to_spectrum=*/true, /*aligned=*/(h->S % 2) == 0, h->nm16, h->stream));
     else
-        HIP_TRY(h, launch_front_generic(p, h->stream));
+        HIP_TRY(h, launch_front_generic(p, /*fused=*/false, h->stream));
     h->block_wcnd = wcnd;
     return MFX_OK;
 }
@@ -864,7 +864,7 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
     HIP_TRY(h, upload(h->d_segs, segs));
     if (h->cfg.norm != MFX_NORM_NONE) HIP_TRY(h, h->d_stats_batch.alloc((size_t)n_utt * 3 * 2 * h->cols));
     // scratch for the compact statics (allocated here so that mfx_batch_run_device itself never allocates)
-    if (h->fast512 && h->l1 > 0 && h->cols <= 16 && h->d_static16.n < (size_t)row * 16)
+    if (h->l1 > 0 && h->cols <= 16 && h->d_static16.n < (size_t)row * 16)
         HIP_TRY(h, h->d_static16.alloc((size_t)row * 16));
     return MFX_OK;
 }
@@ -892,22 +892,31 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
     p.feat = d_out;
     p.feat_pitch = h->width;
 
+    // Which front end: the 512-point register kernel, else the fused wave-per-frame kernel when its
+    // LDS fits, else spectrum through an HBM slab + melcep.
+    const bool fused512 = h->fast512 && h->fused_ok;
+    // (for 2048 points and more the single-kernel form loses: one frame occupies a whole block, and the
+    // serial walk over the widest mel filters then idles it -- spectrum + melcep keeps 4 frames per block)
+    const bool fusedgen = !fused512 && h->W2 <= 1024 && front_wave_lds_bytes(p, true) <= 160 * 1024;
     // With deltas on, the front end writes its statics as compact 64-byte rows into a scratch buffer
     // and the delta kernel emits whole [static | d | dd] rows: every HBM write is then a full line
     // (13-float row pieces at a 156-byte pitch cost 1.5x their size in 32-byte sectors).
     const bool norm_before = h->cfg.norm != MFX_NORM_NONE && !h->cfg.norm_after_dyn;
-    const bool via_scratch = h->fast512 && h->fused_ok && h->l1 > 0 && h->cols <= 16 && p.dct_mode == 1 && !norm_before;
+    const bool via_scratch = ((fused512 && p.dct_mode == 1) || fusedgen) && h->l1 > 0 && h->cols <= 16 && !norm_before &&
+                             h->d_static16.n >= (size_t)h->total_rows * 16;
     if (via_scratch) {
-        if (h->d_static16.n < (size_t)h->total_rows * 16) HIP_TRY(h, h->d_static16.alloc((size_t)h->total_rows * 16));
         p.feat = h->d_static16.p;
         p.feat_pitch = 16;
     }
-    if (h->fast512 && h->fused_ok) {
+    if (fused512) {
         p.spec = h->d_spec.p; // unused by the fused kernel; a -DMFX_STAMPS dev build drops its cycle sums here
         ProfScope ps(h);
         HIP_TRY(h, launch_front512(p, /*to_spectrum=*/false, h->batch_aligned, h->nm16, h->stream));
+    } else if (fusedgen) {
+        ProfScope ps(h);
+        HIP_TRY(h, launch_front_generic(p, /*fused=*/true, h->stream));
     } else {
-        // generic sizes: magnitudes go through an HBM slab, then melcep
+        // magnitudes go through an HBM slab, then melcep
         const int64_t slab_rows_max = 1 << 17;
         const int64_t slab_rows = std::min<int64_t>(h->total_rows, slab_rows_max);
         if (h->d_spec_slab.n < (size_t)slab_rows * h->spec_pitch)
@@ -932,15 +941,15 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
                 if (h->fast512)
                     HIP_TRY(h, launch_front512(q, /*to_spectrum=*/true, h->batch_aligned, h->nm16, h->stream));
                 else
-                    HIP_TRY(h, launch_front_generic(q, h->stream));
+                    HIP_TRY(h, launch_front_generic(q, /*fused=*/false, h->stream));
             }
             MelcepParams mp;
             std::memset(&mp, 0, sizeof(mp));
             mp.spec = h->d_spec_slab.p;
             mp.spec_pitch = h->spec_pitch;
             mp.n_rows = rows;
-            mp.feat = d_out + row0 * (int64_t)h->width;
-            mp.feat_pitch = h->width;
+            mp.feat = p.feat + row0 * (int64_t)p.feat_pitch;
+            mp.feat_pitch = p.feat_pitch;
             mp.fft_size = h->W2;
             mp.mel_w = h->d_mel_w.p;
             mp.mel_beg = h->d_mel_beg.p;

@@ -53,7 +53,7 @@ struct FrontParams {
     const float *window;      // [W2] zero padded                      (generic)
     const float *winpair;     // [16][16][2] window laid out per lane  (512 fast path)
     const float *twid_pass;   // [16][16][2] W_256^(l*k)               (512 fast path)
-    const float *twid_half;   // [W2/4][2]   W_{W2/2}^k                (generic Stockham)
+    const float *twid_half;   // [W2/2][2]   W_{W2/2}^k, k < W2/2       (generic Stockham, radix 4 needs 3k)
     const float *twid_split;  // [W2/2+1][2] -i * W_{W2}^k             (real split)
     const float *mel_w;       // [2][W2]
     const int32_t *mel_beg;   // [nb+2]
@@ -117,7 +117,9 @@ struct NormParams {
 
 // All launchers are asynchronous on `stream` and return the launch status.
 hipError_t launch_front512(const FrontParams &p, bool to_spectrum, bool aligned, int nm16, hipStream_t stream);
-hipError_t launch_front_generic(const FrontParams &p, hipStream_t stream);
+// fused = mel/log/DCT in the same kernel (statics to p.feat); else magnitudes to p.spec
+hipError_t launch_front_generic(const FrontParams &p, bool fused, hipStream_t stream);
+size_t front_wave_lds_bytes(const FrontParams &p, bool fused);
 hipError_t launch_melcep(const MelcepParams &p, hipStream_t stream);
 hipError_t launch_delta(const DeltaParams &p, hipStream_t stream);
 hipError_t launch_norm_stats(const NormParams &p, hipStream_t stream);

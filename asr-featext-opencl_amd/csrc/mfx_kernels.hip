@@ -101,7 +101,10 @@ __device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int
         for (int k = b0; k < b1; ++k) acc += w[k] * mag[k];
         melbuf[m] = logf(fmaxf(acc, 1e-30f));
     }
-    wave_sync();
+    if (G > 64)
+        __syncthreads();
+    else
+        wave_sync();
     if (s_dct) {
         for (int c = g; c < cols; c += G) {
             float acc = 0.f;
@@ -576,25 +579,63 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
 
 // ------------------------------------------------------------------------------------------------
 // Generic front end: any power-of-two FFT length 64..4096, mono or stereo, any alignment.
-// One 256-thread block per frame at a time (grid-stride over the frames of its chunks):
-// half-size complex Stockham radix-2 in LDS + real split; magnitudes to HBM.
+// One WAVE per frame (4 waves per block, each walking its own chunks): half-size complex Stockham
+// FFT in the wave's own LDS buffers -- radix-4 stages, one radix-2 stage when log2 is odd, only
+// wave-level synchronisation -- then the real split and the magnitudes.
+//   FUSED: mel -> log -> DCT straight from LDS (no spectrum round trip through HBM), statics out;
+//   else : magnitudes to the HBM spectrum buffer (streaming set_input).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_front_generic(FrontParams p)
+// G = threads that share one frame: 64 (a wave; wave-level synchronisation only) or 256 (the whole
+// block; for long transforms, where one frame per wave would leave too few waves per CU for its LDS).
+template <bool FUSED, int G>
+__global__ void __launch_bounds__(256) k_front_wave(FrontParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x;
-    const int W2 = p.fft_size, M = W2 >> 1;
-    float2 *bufA = (float2 *)smem;
+    const int tid = threadIdx.x, wave = tid / G, lane = tid % G; // 'wave' = frame group inside the block
+    constexpr int NG = 256 / G;                               // frame groups per block
+    auto group_sync = [&]() {
+        if (G == 64)
+            wave_sync();
+        else
+            __syncthreads();
+    };
+    const int W2 = p.fft_size, M = W2 >> 1, nbins = M + 1;
+    const int bins_pad = (nbins + 3) & ~3;
+    const int nb = p.num_banks, dl = p.dct_len;
+    // shared tables (FUSED only), then per wave: two complex buffers of M points + mel scratch
+    float *s_w0 = smem;
+    float *s_w1 = s_w0 + (FUSED ? bins_pad : 0);
+    int *s_beg = (int *)(s_w1 + (FUSED ? bins_pad : 0));
+    const int beg_pad = FUSED ? ((nb + 2 + 3) & ~3) : 0;
+    float *s_dct = (float *)(s_beg + beg_pad);
+    const int dct_floats = (FUSED && p.dct) ? nb * dl : 0;
+    const int dct_pad = (dct_floats + 3) & ~3;
+    const int nb_pad = FUSED ? ((nb + 3) & ~3) : 0;
+    float *s_wave = s_dct + dct_pad + wave * (4 * M + nb_pad);
+    float2 *bufA = (float2 *)s_wave;
     float2 *bufB = bufA + M;
-    const float2 *tw = (const float2 *)p.twid_half;   // W_M^k, k < M/2
+    float *s_mel = s_wave + 4 * M;
+    if (FUSED) {
+        for (int i = tid; i < nbins; i += 256) {
+            s_w0[i] = p.mel_w[i];
+            s_w1[i] = p.mel_w[W2 + i];
+        }
+        for (int i = tid; i < nb + 2; i += 256) s_beg[i] = p.mel_beg[i];
+        for (int i = tid; i < dct_floats; i += 256) s_dct[i] = p.dct[i];
+    }
+    __syncthreads();
+
+    const float2 *tw = (const float2 *)p.twid_half;   // W_M^k, k < M
     const float2 *cs = (const float2 *)p.twid_split;  // -i W_{W2}^k, k <= M
     const int ch_n = p.channels;
+    const float scale = p.scale; // 0.5 / W2
 
-    for (int c = blockIdx.x; c < p.n_chunks; c += gridDim.x) {
+    for (int c = blockIdx.x * NG + wave; c < p.n_chunks; c += gridDim.x * NG) {
         const Chunk ch = p.chunks[c];
         for (int f = 0; f < ch.n_frames && (ch.out_row + f) < p.row_limit; ++f) {
             const int64_t s0 = ch.pcm_off + (int64_t)f * p.shift;
-            for (int n = tid; n < M; n += 256) {
+            // ---- framing + window: z[n] = (w[2n] x[2n], w[2n+1] x[2n+1]), zero beyond the window
+            for (int n = lane; n < M; n += G) {
                 float v[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
@@ -603,38 +644,61 @@ __global__ void __launch_bounds__(256) k_front_generic(FrontParams p)
                     if (j < p.window_size) {
                         const int64_t s = s0 + j;
                         int xi;
-                        if (ch_n == 2) {
-                            // stereo -> mono (L + R) >> 1 in integer arithmetic
-                            xi = ((int)p.pcm[2 * s] + (int)p.pcm[2 * s + 1]) >> 1;
-                        } else {
+                        if (ch_n == 2)
+                            xi = ((int)p.pcm[2 * s] + (int)p.pcm[2 * s + 1]) >> 1; // stereo -> mono (L + R) >> 1
+                        else
                             xi = (int)p.pcm[s];
-                        }
                         x = p.window[j] * (float)xi;
                     }
                     v[e] = x;
                 }
                 bufA[n] = make_float2(v[0], v[1]);
             }
-            __syncthreads();
+            group_sync();
+            // ---- Stockham autosort FFT of M complex points
             float2 *x = bufA, *y = bufB;
-            for (int n = M, st = 1; n > 1; n >>= 1, st <<= 1) {
-                const int m = n >> 1;
-                const int tstep = M / n;
-                for (int idx = tid; idx < (M >> 1); idx += 256) {
-                    const int pp = idx / st, q = idx - pp * st;
-                    const float2 w = tw[pp * tstep];
-                    const float2 a = x[q + st * pp], b = x[q + st * (pp + m)];
-                    y[q + st * (2 * pp)] = make_float2(a.x + b.x, a.y + b.y);
-                    y[q + st * (2 * pp + 1)] = cmul(make_float2(a.x - b.x, a.y - b.y), w);
+            int len = M, st = 1, lg_st = 0; // st = 1 << lg_st (all sizes are powers of two: shifts, no division)
+            while (len > 1) {
+                if ((len & 3) == 0) {
+                    const int n1 = len >> 2, tstep = st; // M / len == st
+                    for (int idx = lane; idx < (M >> 2); idx += G) {
+                        const int pp = idx >> lg_st, q = idx & (st - 1);
+                        const float2 w1 = tw[pp * tstep], w2 = tw[2 * pp * tstep], w3 = tw[3 * pp * tstep];
+                        const float2 a = x[q + st * pp], b = x[q + st * (pp + n1)];
+                        const float2 cc = x[q + st * (pp + 2 * n1)], d = x[q + st * (pp + 3 * n1)];
+                        const float2 apc = make_float2(a.x + cc.x, a.y + cc.y), amc = make_float2(a.x - cc.x, a.y - cc.y);
+                        const float2 bpd = make_float2(b.x + d.x, b.y + d.y);
+                        const float2 jbmd = make_float2(-(b.y - d.y), b.x - d.x); // i * (b - d)
+                        y[q + st * (4 * pp)] = make_float2(apc.x + bpd.x, apc.y + bpd.y);
+                        y[q + st * (4 * pp + 1)] = cmul(make_float2(amc.x - jbmd.x, amc.y - jbmd.y), w1);
+                        y[q + st * (4 * pp + 2)] = cmul(make_float2(apc.x - bpd.x, apc.y - bpd.y), w2);
+                        y[q + st * (4 * pp + 3)] = cmul(make_float2(amc.x + jbmd.x, amc.y + jbmd.y), w3);
+                    }
+                    len >>= 2;
+                    st <<= 2;
+                    lg_st += 2;
+                } else {
+                    const int n1 = len >> 1, tstep = st;
+                    for (int idx = lane; idx < (M >> 1); idx += G) {
+                        const int pp = idx >> lg_st, q = idx & (st - 1);
+                        const float2 w = tw[pp * tstep];
+                        const float2 a = x[q + st * pp], b = x[q + st * (pp + n1)];
+                        y[q + st * (2 * pp)] = make_float2(a.x + b.x, a.y + b.y);
+                        y[q + st * (2 * pp + 1)] = cmul(make_float2(a.x - b.x, a.y - b.y), w);
+                    }
+                    len >>= 1;
+                    st <<= 1;
+                    lg_st += 1;
                 }
-                __syncthreads();
+                group_sync();
                 float2 *t = x;
                 x = y;
                 y = t;
             }
-            float *dst = p.spec + (ch.out_row + f) * (int64_t)p.spec_pitch;
-            const float scale = p.scale; // 0.5 / W2
-            for (int k = tid; k <= M; k += 256) {
+            // ---- real split + magnitude into the other buffer (as floats)
+            float *mag = (float *)y;
+            float *dst_spec = FUSED ? nullptr : p.spec + (ch.out_row + f) * (int64_t)p.spec_pitch;
+            for (int k = lane; k <= M; k += G) {
                 const float2 zk = x[k & (M - 1)];
                 const float2 zm = x[(M - k) & (M - 1)];
                 const float sr = zk.x + zm.x, si = zk.y - zm.y;
@@ -642,9 +706,18 @@ __global__ void __launch_bounds__(256) k_front_generic(FrontParams p)
                 const float2 w = cs[k];
                 const float xr = sr + (w.x * dr - w.y * di);
                 const float xi = si + (w.x * di + w.y * dr);
-                dst[k] = sqrtf(xr * xr + xi * xi) * scale;
+                const float m = __builtin_amdgcn_sqrtf(xr * xr + xi * xi) * scale;
+                if (FUSED)
+                    mag[k] = m;
+                else
+                    dst_spec[k] = m;
             }
-            __syncthreads();
+            group_sync();
+            if (FUSED) {
+                mel_log_dct<G>(mag, s_mel, lane, s_w0, s_w1, s_beg, p.dct ? s_dct : nullptr, nb, dl, p.cols,
+                                p.feat + (ch.out_row + f) * (int64_t)p.feat_pitch);
+                group_sync();
+            }
         }
     }
 }
@@ -938,14 +1011,45 @@ hipError_t launch_front512(const FrontParams &p, bool to_spectrum, bool aligned,
     return nm13 ? launch512<false, false, 13>(p, stream) : launch512<false, false, 16>(p, stream);
 }
 
-hipError_t launch_front_generic(const FrontParams &p, hipStream_t stream)
+size_t front_wave_lds_bytes(const FrontParams &p, bool fused)
+{
+    const int M = p.fft_size >> 1, nbins = M + 1, bins_pad = (nbins + 3) & ~3;
+    size_t f = 0;
+    if (fused) {
+        f += 2 * (size_t)bins_pad + ((p.num_banks + 2 + 3) & ~3);
+        f += ((p.dct ? (size_t)p.num_banks * p.dct_len : 0) + 3) & ~(size_t)3;
+    }
+    const int groups = p.fft_size >= 2048 ? 1 : 4; // frames in flight per block (see launch_front_generic)
+    f += groups * ((size_t)4 * M + (fused ? ((p.num_banks + 3) & ~3) : 0));
+    return f * sizeof(float);
+}
+
+hipError_t launch_front_generic(const FrontParams &p, bool fused, hipStream_t stream)
 {
     if (p.n_chunks <= 0) return hipSuccess;
-    const size_t lds = (size_t)p.fft_size * 2 * sizeof(float); // two buffers of W2/2 complex
-    int blocks = p.n_chunks;
+    const size_t lds = front_wave_lds_bytes(p, fused);
+    const bool wide = p.fft_size >= 2048; // one frame per block instead of one per wave
+    const void *fn = wide ? (fused ? (const void *)k_front_wave<true, 256> : (const void *)k_front_wave<false, 256>)
+                          : (fused ? (const void *)k_front_wave<true, 64> : (const void *)k_front_wave<false, 64>);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const int per_block = wide ? 1 : 4;
+    int blocks = (p.n_chunks + per_block - 1) / per_block;
     const int cap = num_cus() * 8;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(k_front_generic, dim3(blocks), dim3(256), lds, stream, p);
+    if (wide) {
+        if (fused)
+            hipLaunchKernelGGL((k_front_wave<true, 256>), dim3(blocks), dim3(256), lds, stream, p);
+        else
+            hipLaunchKernelGGL((k_front_wave<false, 256>), dim3(blocks), dim3(256), lds, stream, p);
+    } else {
+        if (fused)
+            hipLaunchKernelGGL((k_front_wave<true, 64>), dim3(blocks), dim3(256), lds, stream, p);
+        else
+            hipLaunchKernelGGL((k_front_wave<false, 64>), dim3(blocks), dim3(256), lds, stream, p);
+    }
     return hipGetLastError();
 }
 
