@@ -32,6 +32,8 @@ WORKLOADS = {
     # name: (n_utt, utt_samples, sample_rate, W, S, fft, nb, nc, dyn)
     "C2": dict(n_utt=1000, utt_samples=160000, sr=16000.0, W=400, S=160, fft=0, nb=40, nc=13, dyn=2,
                desc="1000 synthetic 16 kHz utterances x 10 s, 25 ms/10 ms, 512-pt FFT, 40 mel, 13 MFCC + d + dd"),
+    "T": dict(n_utt=8, utt_samples=16000, sr=16000.0, W=400, S=160, fft=0, nb=40, nc=13, dyn=2,
+              desc="tiny test workload: 8 synthetic 16 kHz utterances x 1 s (launch-path tests only)"),
     "C3": dict(n_utt=1, utt_samples=57600000, sr=16000.0, W=400, S=160, fft=1024, nb=80, nc=13, dyn=0,
                desc="one 1-hour 16 kHz stream, 1024-pt FFT, 80 mel, 13 MFCC"),
     "C5": dict(n_utt=200, utt_samples=441000, sr=44100.0, W=1102, S=441, fft=0, nb=128, nc=40, dyn=2,
@@ -152,13 +154,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # test knobs (rehearsing the N>1 path on a 1-GPU box): MFX_BENCH_DEVICE pins every rank to one
+    # device, MFX_BENCH_BACKEND=gloo replaces RCCL for the barrier / max-over-ranks
+    dev_index = int(os.environ.get("MFX_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("MFX_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     pkg = G.load_package()
     wl = WORKLOADS[args.workload]
@@ -168,7 +177,7 @@ def main():
     # ---- synthetic input resident in HBM (per rank: its own shard of utterances)
     pcm = synth_pcm_torch(torch, wl["n_utt"], wl["utt_samples"], wl["sr"], seed=rank, device=device)
     m = pkg.MfccHip(wl["utt_samples"] + 1000, W, S, wl["nb"], wl["sr"], 64.0, wl["sr"] / 2, wl["nc"], False, 22.0,
-                    pkg.NORM_NONE, wl["dyn"], 3, 3, True, device=local_rank, fft_size=wl["fft"])
+                    pkg.NORM_NONE, wl["dyn"], 3, 3, True, device=dev_index, fft_size=wl["fft"])
     m.set_window(window)
     offsets = np.arange(wl["n_utt"], dtype=np.int64) * wl["utt_samples"]
     lengths = np.full(wl["n_utt"], wl["utt_samples"], dtype=np.int64)
@@ -198,7 +207,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     launches, kernel_ms = m.profile_read(reset=True)

@@ -424,3 +424,27 @@ def test_cpp_driver_text_output(orc, a0001, tmp_path):
     # column 0 is the frame time: 0.5*window + t*shift (ASR_OCL.cpp:224-225,254)
     np.testing.assert_allclose(got[:, 0], 0.0125 + 0.01 * np.arange(711), atol=1e-6)
     assert np.abs(got[:, 1:] - want).max() <= 1e-4 * np.abs(want).max() + 1e-6   # + %f quantisation
+
+
+def test_bench_two_rank_launch_path(tmp_path):
+    """bench.py's N>1 path (one process per rank under torch.distributed.run, barrier, max over ranks,
+    whole-job aggregate) rehearsed with 2 ranks on this box's single GPU: gloo instead of RCCL, both
+    ranks pinned to device 0, tiny workload."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MFX_BENCH_DEVICE="0", MFX_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "T", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]           # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
+    assert d["config"]["frames_per_gpu_per_step"] == 8 * 98
+    # whole-job value = frames of all ranks / max-over-ranks step time
+    assert abs(d["value"] - 2 * 8 * 98 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert "roofline" in d and "cpu_baseline" not in d
