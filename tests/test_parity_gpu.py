@@ -448,3 +448,52 @@ def test_bench_two_rank_launch_path(tmp_path):
     # whole-job value = frames of all ranks / max-over-ranks step time
     assert abs(d["value"] - 2 * 8 * 98 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert "roofline" in d and "cpu_baseline" not in d
+
+
+# ---------------------------------------------------------------------------------------------
+# randomized configuration sweep (seeded): window/shift/filterbank/cepstra/delta/normalisation shapes
+# the fixed cases above do not hit -- odd shifts, windows that are not multiples of 32, FFT overrides,
+# few or many filters, narrow bands, every delta width
+# ---------------------------------------------------------------------------------------------
+
+def _random_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(n):
+        fft = int(rng.choice([256, 512, 512, 512, 1024, 2048]))
+        W = int(rng.integers(fft // 2 + 1, fft + 1))
+        S = int(rng.integers(max(W // 8, 8), W // 2 + 1))
+        sr = float(rng.choice([8000.0, 16000.0, 22050.0, 44100.0]))
+        nb = int(rng.integers(8, 64))
+        nc = int(rng.choice([0, 5, 12, 13, 20]))
+        nc = min(nc, nb - 1)
+        c0 = bool(rng.integers(0, 2)) and nc > 0
+        dyn = int(rng.integers(0, 3))
+        l1, l2 = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        low = float(rng.choice([0.0, 64.0, 300.0]))
+        high = float(sr / 2 * rng.choice([1.0, 0.9, 0.5]))
+        norm = int(rng.choice([0, 0, 1, 2]))
+        cases.append(dict(fft=fft, W=W, S=S, sr=sr, nb=nb, nc=nc, c0=c0, dyn=dyn, l1=l1, l2=l2, low=low, high=high,
+                          norm=norm, seed=1000 + i))
+    return cases
+
+
+@pytest.mark.parametrize("case", _random_cases(24, 20260104), ids=lambda c: "fft%d_W%d_S%d_nb%d_nc%d_dyn%d_n%d" % (
+    c["fft"], c["W"], c["S"], c["nb"], c["nc"], c["dyn"], c["norm"]))
+def test_random_configuration(pkg, orc, case):
+    c = case
+    n = 40 * c["S"] + c["W"] + int(c["seed"] % 7) * 13
+    pcm = synth_utterance(3 * n, c["seed"], sr=c["sr"])
+    m, cfg, w = make_pair(pkg, orc, n, W=c["W"], S=c["S"], nb=c["nb"], sr=c["sr"], low=c["low"], high=c["high"],
+                          nc=c["nc"], c0=c["c0"], norm=c["norm"], dyn=c["dyn"], l1=c["l1"], l2=c["l2"])
+    assert m.fft_size() == c["fft"]
+    g = groups_of(c["dyn"])
+    # CMN/CVN: the output is rescaled by 1/sigma of each column, which amplifies the float32 noise floor of
+    # the un-normalised features (a few 1e-6 of their scale) by scale/sigma -- large for the nearly
+    # constant delta-delta columns -- so the comparison is looser there; un-normalised configurations
+    # keep the 1e-4 / 1e-5 bar
+    tol = dict(tol_max=1e-3, tol_l2=2e-4) if c["norm"] else {}
+    assert_close(m.process_stream(pcm), orc.run_utterance(cfg, pcm, w), "stream", groups=g, **tol)
+    if not c["norm"]:   # batch normalisation is per utterance, the reference's is per block
+        m.batch_plan([0], [pcm.size])
+        assert_close(m.batch_run_host(pcm), orc.run_utterance(cfg, pcm, w, bug_compat=False), "batch", groups=g)
