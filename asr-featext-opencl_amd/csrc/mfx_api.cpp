@@ -101,7 +101,14 @@ struct mfx_handle {
     std::vector<Chunk> h_chunks;
     DevBuf<Chunk> d_chunks;
     DevBuf<Segment> d_segs;
-    DevBuf<float> d_stats_batch, d_spec_slab, d_static16; // d_static16: compact [rows][16] statics between front end and delta
+    DevBuf<float> d_stats_batch, d_spec_slab;
+    DevBuf<float> d_static16[2]; // compact [rows][16] statics between front end and delta (double buffered for overlap)
+    // optional overlap of the delta/normalisation tail of batch i with the front end of batch i+1
+    bool overlap = false;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
+    bool tail_pending[2] = {false, false};
+    unsigned batch_seq = 0;
     int tiles_max = 0;
     bool batch_aligned = true;
 
@@ -327,7 +334,16 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_segs.release();
     h->d_stats_batch.release();
     h->d_spec_slab.release();
-    h->d_static16.release();
+    h->d_static16[0].release();
+    h->d_static16[1].release();
+    if (h->stream2) {
+        (void)hipStreamSynchronize(h->stream2);
+        (void)hipStreamDestroy(h->stream2);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (h->ev_front[i]) (void)hipEventDestroy(h->ev_front[i]);
+        if (h->ev_tail[i]) (void)hipEventDestroy(h->ev_tail[i]);
+    }
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -510,6 +526,8 @@ extern "C" int mfx_synchronize(mfx_handle *h)
 {
     if (!h) return MFX_ERR_ARG;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->stream2) HIP_TRY(h, hipStreamSynchronize(h->stream2));
+    h->tail_pending[0] = h->tail_pending[1] = false;
     return MFX_OK;
 }
 
@@ -864,8 +882,9 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
     HIP_TRY(h, upload(h->d_segs, segs));
     if (h->cfg.norm != MFX_NORM_NONE) HIP_TRY(h, h->d_stats_batch.alloc((size_t)n_utt * 3 * 2 * h->cols));
     // scratch for the compact statics (allocated here so that mfx_batch_run_device itself never allocates)
-    if (h->l1 > 0 && h->cols <= 16 && h->d_static16.n < (size_t)row * 16)
-        HIP_TRY(h, h->d_static16.alloc((size_t)row * 16));
+    for (int b = 0; b < (h->overlap ? 2 : 1); ++b)
+        if (h->l1 > 0 && h->cols <= 16 && h->d_static16[b].n < (size_t)row * 16)
+            HIP_TRY(h, h->d_static16[b].alloc((size_t)row * 16));
     return MFX_OK;
 }
 
@@ -902,12 +921,20 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
     // and the delta kernel emits whole [static | d | dd] rows: every HBM write is then a full line
     // (13-float row pieces at a 156-byte pitch cost 1.5x their size in 32-byte sectors).
     const bool norm_before = h->cfg.norm != MFX_NORM_NONE && !h->cfg.norm_after_dyn;
+    // Overlap (opt-in, mfx_batch_overlap): the delta/normalisation tail runs on a second stream behind an
+    // event, so the memory-bound tail of batch i shares the GPU with the compute-bound front end of
+    // batch i+1; the statics scratch is double buffered and the front end of batch i+2 waits for tail i.
+    const int sb = h->overlap ? (int)(h->batch_seq & 1) : 0;
     const bool via_scratch = ((fused512 && p.dct_mode == 1) || fusedgen) && h->l1 > 0 && h->cols <= 16 && !norm_before &&
-                             h->d_static16.n >= (size_t)h->total_rows * 16;
+                             h->d_static16[sb].n >= (size_t)h->total_rows * 16;
+    const bool split_tail = h->overlap && via_scratch;
+    hipStream_t tail_stream = split_tail ? h->stream2 : h->stream;
     if (via_scratch) {
-        p.feat = h->d_static16.p;
+        p.feat = h->d_static16[sb].p;
         p.feat_pitch = 16;
     }
+    if (split_tail && h->tail_pending[sb]) // tail of batch i-2 still reads this scratch buffer
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_tail[sb], 0));
     if (fused512) {
         p.spec = h->d_spec.p; // unused by the fused kernel; a -DMFX_STAMPS dev build drops its cycle sums here
         ProfScope ps(h);
@@ -962,6 +989,16 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
         }
     }
 
+    if (split_tail) {
+        HIP_TRY(h, hipEventRecord(h->ev_front[sb], h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_front[sb], 0));
+    }
+    struct StreamSwap { // the tail kernels below launch on h->stream: point it at the tail stream meanwhile
+        mfx_handle *h;
+        hipStream_t keep;
+        StreamSwap(mfx_handle *hh, hipStream_t s) : h(hh), keep(hh->stream) { h->stream = s; }
+        ~StreamSwap() { h->stream = keep; }
+    } swap_guard(h, tail_stream);
     const bool norm = h->cfg.norm != MFX_NORM_NONE;
     if (norm && !h->cfg.norm_after_dyn) {
         rc = run_norm(h, d_out, h->width, 0, h->d_segs.p, h->n_utt, nullptr, 0, h->d_stats_batch.p, false);
@@ -970,7 +1007,7 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
     if (h->l1 > 0) {
         DeltaParams dp;
         std::memset(&dp, 0, sizeof(dp));
-        dp.src = via_scratch ? h->d_static16.p : d_out;
+        dp.src = via_scratch ? h->d_static16[sb].p : d_out;
         dp.src_pitch = via_scratch ? 16 : h->width;
         dp.out = d_out;
         dp.out_pitch = h->width;
@@ -990,6 +1027,32 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
             if (rc != MFX_OK) return rc;
         }
     }
+    if (split_tail) {
+        HIP_TRY(h, hipEventRecord(h->ev_tail[sb], tail_stream));
+        h->tail_pending[sb] = true;
+    }
+    ++h->batch_seq;
+    return MFX_OK;
+}
+
+extern "C" int mfx_batch_overlap(mfx_handle *h, int enable)
+{
+    if (!h) return MFX_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = mfx_synchronize(h);
+    if (rc != MFX_OK) return rc;
+    if (enable && !h->stream2) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_front[i], hipEventDisableTiming));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_tail[i], hipEventDisableTiming));
+        }
+    }
+    h->overlap = enable != 0;
+    h->tail_pending[0] = h->tail_pending[1] = false;
+    if (h->overlap && h->total_rows > 0 && h->l1 > 0 && h->cols <= 16)
+        for (int b = 0; b < 2; ++b)
+            if (h->d_static16[b].n < (size_t)h->total_rows * 16) HIP_TRY(h, h->d_static16[b].alloc((size_t)h->total_rows * 16));
     return MFX_OK;
 }
 
@@ -1010,6 +1073,7 @@ extern "C" int mfx_batch_run_host(mfx_handle *h, const int16_t *pcm, int64_t pcm
     e = hipMemcpyAsync(d_pcm.p, pcm, n_in * sizeof(int16_t), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
         rc = mfx_batch_run_device(h, d_pcm.p, pcm_samples_total, d_out.p);
+        if (rc == MFX_OK && h->stream2) (void)hipStreamSynchronize(h->stream2); // overlapped tail, if any
         if (rc == MFX_OK && h->total_rows > 0)
             e = hipMemcpyAsync(out, d_out.p, (size_t)h->total_rows * h->width * sizeof(float), hipMemcpyDeviceToHost,
                                h->stream);

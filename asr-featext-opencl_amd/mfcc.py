@@ -54,7 +54,7 @@ EXPORTED_SYMBOLS = (
     "mfx_set_window", "mfx_set_input", "mfx_flush", "mfx_set_alpha", "mfx_apply",
     "mfx_get_output_data_width", "mfx_get_output_data", "mfx_get_input_buffer_size",
     "mfx_estimated_window_count", "mfx_max_frames_out", "mfx_fft_size",
-    "mfx_batch_frames", "mfx_batch_plan", "mfx_batch_run_device", "mfx_batch_run_host",
+    "mfx_batch_frames", "mfx_batch_plan", "mfx_batch_run_device", "mfx_batch_run_host", "mfx_batch_overlap",
     "mfx_set_stream", "mfx_synchronize", "mfx_profile_enable", "mfx_profile_read",
     "mfx_dominant_kernel_name", "mfx_debug_read",
     "mfx_host_mel_table", "mfx_host_dct_matrix", "mfx_host_frame_count",
@@ -109,6 +109,7 @@ def load_library():
     L.mfx_batch_plan.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.mfx_batch_run_device.argtypes = [vp, vp, i64, vp]
     L.mfx_batch_run_host.argtypes = [vp, sp, i64, fp]
+    L.mfx_batch_overlap.argtypes = [vp, C.c_int]
     L.mfx_set_stream.argtypes = [vp, vp]
     L.mfx_synchronize.argtypes = [vp]
     L.mfx_profile_enable.argtypes = [vp, C.c_int]
@@ -290,6 +291,10 @@ class MfccHip:
         self._chk(self._L.mfx_batch_run_host(self._h, pcm.ctypes.data_as(C.POINTER(C.c_int16)), total,
                                              out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
+
+    def batch_overlap(self, enable=True):
+        """Let the delta tail of a batch overlap the next batch's front end (results complete after synchronize())."""
+        self._chk(self._L.mfx_batch_overlap(self._h, int(bool(enable))))
 
     def set_stream(self, hip_stream_handle):
         self._chk(self._L.mfx_set_stream(self._h, C.c_void_p(int(hip_stream_handle))))

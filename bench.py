@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true",
+                    help="let the delta tail of a step overlap the next step's front end (mfx_batch_overlap); measured "
+                         "neutral on MI355X -- the front end's waves fill the register file -- so off by default")
     args = ap.parse_args()
 
     import torch
@@ -181,6 +184,8 @@ def main():
     m.set_window(window)
     offsets = np.arange(wl["n_utt"], dtype=np.int64) * wl["utt_samples"]
     lengths = np.full(wl["n_utt"], wl["utt_samples"], dtype=np.int64)
+    if args.overlap:
+        m.batch_overlap(True)   # consecutive steps pipeline: tail of step i beside the front end of step i+1
     rows, total_rows = m.batch_plan(offsets, lengths)
     width = m.get_output_data_width()
     out = torch.empty((total_rows, width), dtype=torch.float32, device=device)
@@ -256,7 +261,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %s; per GPU, resident in HBM" % (args.workload, wl["desc"]),
                    "frames_per_gpu_per_step": frames_rank, "utterances_per_gpu": wl["n_utt"],
-                   "sharding": "independent utterance shards per rank, no collective"},
+                   "sharding": "independent utterance shards per rank, no collective",
+                   "step_pipelining": "delta tail of step i overlaps front end of step i+1" if args.overlap else "off"},
         "roofline": roofline,
     }
 

@@ -137,6 +137,12 @@ int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offsets, const i
  * entry the roofline numbers are measured on. */
 int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_total, float *d_out);
 
+/* Opt-in pipelining of consecutive batches: with enable=1 the delta / normalisation tail of a batch runs
+ * on a second internal stream, so it overlaps the front end of the NEXT mfx_batch_run_device call.
+ * Results of a batch are then complete only after mfx_synchronize() (or a device-wide synchronise),
+ * not in order on the handle's stream.  Off by default (strict stream order). */
+int mfx_batch_overlap(mfx_handle *h, int enable);
+
 /* Convenience: same, from/to HOST buffers (pinned staging + H2D, run, D2H, synchronises). */
 int mfx_batch_run_host(mfx_handle *h, const int16_t *pcm, int64_t pcm_samples_total, float *out);
 

@@ -497,3 +497,38 @@ def test_random_configuration(pkg, orc, case):
     if not c["norm"]:   # batch normalisation is per utterance, the reference's is per block
         m.batch_plan([0], [pcm.size])
         assert_close(m.batch_run_host(pcm), orc.run_utterance(cfg, pcm, w, bug_compat=False), "batch", groups=g)
+
+
+def test_batch_overlap_mode_is_bit_identical(pkg, orc):
+    """mfx_batch_overlap: the delta tail of batch i runs beside the front end of batch i+1 (second stream,
+    double-buffered statics).  Back-to-back batches on different inputs must give exactly the results of
+    the strictly ordered mode."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n_utt, n = 64, 48000
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    pcms = [(4000.0 * torch.randn((n_utt, n), generator=g, device=dev)).round().clamp(-32768, 32767).to(torch.int16)
+            for _ in range(5)]
+    m, cfg, w = make_pair(pkg, orc, n + 1000)
+    rows, total = m.batch_plan(np.arange(n_utt) * n, np.full(n_utt, n))
+    ref = []
+    for x in pcms:
+        o = torch.empty((total, 39), dtype=torch.float32, device=dev)
+        m.batch_run_device(x.data_ptr(), x.numel(), o.data_ptr())
+        m.synchronize()
+        ref.append(o)
+    m.batch_overlap(True)
+    outs = [torch.full((total, 39), float("nan"), dtype=torch.float32, device=dev) for _ in pcms]
+    for x, o in zip(pcms, outs):          # no synchronisation between batches
+        m.batch_run_device(x.data_ptr(), x.numel(), o.data_ptr())
+    m.synchronize()
+    for a, b in zip(outs, ref):
+        assert torch.equal(a, b)
+    m.batch_overlap(False)
+    o = torch.empty((total, 39), dtype=torch.float32, device=dev)
+    m.batch_run_device(pcms[0].data_ptr(), pcms[0].numel(), o.data_ptr())
+    m.synchronize()
+    assert torch.equal(o, ref[0])
+    want = orc.run_utterance(cfg, pcms[2][5].cpu().numpy(), w, bug_compat=False)
+    assert_close(outs[2][rows[5]:rows[5] + want.shape[0]].cpu().numpy(), want, "overlap mode vs oracle", groups=3)
