@@ -98,7 +98,19 @@ __device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int
         const int b0 = s_beg[m], b1 = s_beg[m + 2];
         const float *w = (m & 1) ? s_w1 : s_w0;
         float acc = 0.f;
-        for (int k = b0; k < b1; ++k) acc += w[k] * mag[k];
+        int k = b0;
+        // 8 bins per trip: the 16 LDS reads are issued together, the sum stays in ascending bin order
+        for (; k + 8 <= b1; k += 8) {
+            float wv[8], mv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                wv[u] = w[k + u];
+                mv[u] = mag[k + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += wv[u] * mv[u];
+        }
+        for (; k < b1; ++k) acc += w[k] * mag[k];
         melbuf[m] = logf(fmaxf(acc, 1e-30f));
     }
     if (G > 64)
@@ -108,7 +120,18 @@ __device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int
     if (s_dct) {
         for (int c = g; c < cols; c += G) {
             float acc = 0.f;
-            for (int m = 0; m < nb; ++m) acc += melbuf[m] * s_dct[m * dct_len + c];
+            int m = 0;
+            for (; m + 8 <= nb; m += 8) { // reads batched 8 deep, sum in ascending m
+                float ev[8], dv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    ev[u] = melbuf[m + u];
+                    dv[u] = s_dct[(m + u) * dct_len + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += ev[u] * dv[u];
+            }
+            for (; m < nb; ++m) acc += melbuf[m] * s_dct[m * dct_len + c];
             out_row[c] = acc;
         }
     } else {
