@@ -5,6 +5,8 @@
 //     | <frame time> | v0 | v1 | ... |
 //
 //   afet_hip [options] in1.wav out1.txt [in2.wav out2.txt ...]
+// Inputs: RIFF/WAVE or NIST SPHERE (the reference's sample1.wav), 16-bit PCM.  --htk writes HTK
+// parameter files instead of text (the reference's binary branch is a stub).
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -26,6 +28,7 @@ struct Options {
     float alpha_min = 1.f, alpha_max = 1.f, alpha_step = 1.f;
     int sample_limit = 10000000, device = 0;
     bool bug_compat = true;
+    bool htk = false; // binary output in HTK parameter-file format instead of the reference's text rows
 };
 
 struct Wav {
@@ -36,6 +39,38 @@ struct Wav {
 uint32_t rd32(const unsigned char *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 uint16_t rd16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
+// NIST SPHERE (the reference ships one: sample1.wav): "NIST_1A\n   <header bytes>\n" followed by
+// "key -type value" lines up to "end_head"; 16-bit PCM, sample_byte_format 01 = little endian, 10 = big.
+Wav read_sphere(const std::vector<unsigned char> &b, const std::string &path)
+{
+    const size_t hdr = (size_t)std::atol(reinterpret_cast<const char *>(b.data()) + 8);
+    if (hdr < 16 || hdr > b.size()) throw std::runtime_error("bad SPHERE header in \"" + path + "\"");
+    const std::string text(reinterpret_cast<const char *>(b.data()), hdr);
+    auto field = [&](const char *key, const std::string &dflt) -> std::string {
+        size_t p = text.find(std::string("\n") + key + " ");
+        if (p == std::string::npos) return dflt;
+        p = text.find(' ', p + 1 + std::strlen(key) + 1); // skip "-i" / "-sN"
+        if (p == std::string::npos) return dflt;
+        const size_t e = text.find('\n', p);
+        return text.substr(p + 1, e - p - 1);
+    };
+    Wav w;
+    w.channels = std::atoi(field("channel_count", "1").c_str());
+    w.sample_rate = std::atoi(field("sample_rate", "0").c_str());
+    const long count = std::atol(field("sample_count", "0").c_str());
+    if (std::atoi(field("sample_n_bytes", "2").c_str()) != 2 || field("sample_coding", "pcm").find("pcm") != 0)
+        throw std::runtime_error("only 16-bit PCM SPHERE files are supported");
+    const bool big = field("sample_byte_format", "01") == "10";
+    size_t n = std::min<size_t>((b.size() - hdr) / 2, (size_t)std::max<long>(count, 0) * std::max(w.channels, 1));
+    w.pcm.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char *q = &b[hdr + 2 * i];
+        w.pcm[i] = (int16_t)(big ? ((q[0] << 8) | q[1]) : (q[0] | (q[1] << 8)));
+    }
+    if (w.channels < 1 || w.sample_rate <= 0 || w.pcm.empty()) throw std::runtime_error("Error while loading \"" + path + "\"");
+    return w;
+}
+
 Wav read_wav(const std::string &path)
 {
     FILE *f = std::fopen(path.c_str(), "rb");
@@ -45,8 +80,9 @@ Wav read_wav(const std::string &path)
     size_t n;
     while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) b.insert(b.end(), buf, buf + n);
     std::fclose(f);
+    if (b.size() >= 16 && std::memcmp(b.data(), "NIST_1A", 7) == 0) return read_sphere(b, path);
     if (b.size() < 12 || std::memcmp(b.data(), "RIFF", 4) != 0 || std::memcmp(b.data() + 8, "WAVE", 4) != 0)
-        throw std::runtime_error("\"" + path + "\" is not a RIFF/WAVE file");
+        throw std::runtime_error("\"" + path + "\" is not a RIFF/WAVE or NIST SPHERE file");
     Wav w;
     size_t pos = 12;
     bool have_fmt = false;
@@ -67,6 +103,40 @@ Wav read_wav(const std::string &path)
     }
     if (!have_fmt || w.pcm.empty()) throw std::runtime_error("Error while loading \"" + path + "\"");
     return w;
+}
+
+// HTK parameter file: big-endian header {int32 nSamples, int32 sampPeriod [100 ns], int16 sampSize, int16 parmKind}
+// then nSamples vectors of big-endian float32 (the reference's own binary branch is an empty stub,
+// ASR_OCL.cpp:212,315-319).
+void put_be32(FILE *f, uint32_t v)
+{
+    unsigned char b[4] = {(unsigned char)(v >> 24), (unsigned char)(v >> 16), (unsigned char)(v >> 8), (unsigned char)v};
+    std::fwrite(b, 1, 4, f);
+}
+void put_be16(FILE *f, uint16_t v)
+{
+    unsigned char b[2] = {(unsigned char)(v >> 8), (unsigned char)v};
+    std::fwrite(b, 1, 2, f);
+}
+void write_htk_header(FILE *f, uint32_t n_frames, const Options &o, int width)
+{
+    uint16_t kind = o.ceps > 0 ? 6 /* MFCC */ : 7 /* FBANK */;
+    if (o.ceps > 0 && o.c0) kind |= 0x2000;  // _0
+    if (o.dyn >= 1) kind |= 0x0100;          // _D
+    if (o.dyn >= 2) kind |= 0x0200;          // _A
+    if (o.norm == 1) kind |= 0x0800;         // _Z (zero mean)
+    put_be32(f, n_frames);
+    put_be32(f, (uint32_t)std::llround(o.shift_ms * 1e4));
+    put_be16(f, (uint16_t)(4 * width));
+    put_be16(f, kind);
+}
+void write_rows_htk(FILE *out, const float *rows, int n, int width)
+{
+    for (size_t i = 0; i < (size_t)n * width; ++i) {
+        uint32_t u;
+        std::memcpy(&u, &rows[i], 4);
+        put_be32(out, u);
+    }
 }
 
 void write_rows(FILE *out, const float *rows, int n, int width, int first_frame, long double t0, long double dt)
@@ -99,8 +169,9 @@ void process_file(ParamBase &param, const Options &o, const std::string &in, con
     for (float a = o.alpha_min; a <= o.alpha_max; a = o.alpha_min + (++idx) * o.alpha_step) {
         std::string name = out_name;
         if (o.alpha_max - o.alpha_min >= o.alpha_step) name += "." + std::to_string(a);
-        FILE *fo = std::fopen(name.c_str(), "w");
+        FILE *fo = std::fopen(name.c_str(), o.htk ? "wb" : "w");
         if (!fo) throw std::runtime_error("Can't create output file: " + name);
+        if (o.htk) write_htk_header(fo, 0, o, width); // frame count patched at the end
         outs.emplace_back(a, fo);
     }
     size_t pos = 0;
@@ -112,7 +183,10 @@ void process_file(ParamBase &param, const Options &o, const std::string &in, con
             param.set_alpha(oa.first);
             param.apply();
             param.get_output_data(rows.data(), n);
-            write_rows(oa.second, rows.data(), n, width, total, t0, dt);
+            if (o.htk)
+                write_rows_htk(oa.second, rows.data(), n, width);
+            else
+                write_rows(oa.second, rows.data(), n, width, total, t0, dt);
         }
         total += n;
         pos += n_in;
@@ -123,10 +197,19 @@ void process_file(ParamBase &param, const Options &o, const std::string &in, con
             param.set_alpha(oa.first);
             param.apply();
             param.get_output_data(rows.data(), n);
-            write_rows(oa.second, rows.data(), n, width, total, t0, dt);
+            if (o.htk)
+                write_rows_htk(oa.second, rows.data(), n, width);
+            else
+                write_rows(oa.second, rows.data(), n, width, total, t0, dt);
         }
     total += n;
-    for (auto &oa : outs) std::fclose(oa.second);
+    for (auto &oa : outs) {
+        if (o.htk) {
+            std::fseek(oa.second, 0, SEEK_SET);
+            write_htk_header(oa.second, (uint32_t)total, o, width);
+        }
+        std::fclose(oa.second);
+    }
     std::printf("%s: %d frames x %d\n", in.c_str(), total, width);
 }
 
@@ -165,11 +248,13 @@ int main(int argc, char **argv)
         else if (a == "--sample-limit") o.sample_limit = std::atoi(val());
         else if (a == "--dev") o.device = std::atoi(val());
         else if (a == "--bug-compat") o.bug_compat = std::atoi(val()) != 0;
+        else if (a == "--htk") o.htk = true;
         else if (a == "--help") {
             std::printf("afet_hip [--window-size ms] [--shift ms] [--banks n] [--ceps n] [--c0 0|1] [--norm 0..3]\n"
                         "         [--dyn 0..2] [--l1 n] [--l2 n] [--low-freq hz] [--high-freq hz] [--lift-coef x]\n"
                         "         [--norm-after-dyn 0|1] [--alpha a | --alpha-min a --alpha-max b --alpha-step s]\n"
-                        "         [--sample-limit n] [--dev n] [--bug-compat 0|1]  in.wav out.txt [...]\n");
+                        "         [--sample-limit n] [--dev n] [--bug-compat 0|1] [--htk]  in.wav out.txt [...]\n"
+                        "  inputs: RIFF/WAVE or NIST SPHERE, 16-bit PCM; output: the reference's text rows, or HTK binary\n");
             return 0;
         } else files.push_back(a);
     }

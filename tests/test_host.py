@@ -178,3 +178,17 @@ def test_two_rank_gloo_sharding(tmp_path):
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
     assert r.stdout.count("ok") >= 2
+
+
+def test_sphere_and_riff_fixtures_hold_the_same_pcm(orc):
+    """tests/golden/sample1_sphere.wav (the reference's sample1.wav, NIST_1A header of 1024 bytes,
+    sample_byte_format 01) and sample1_riff.wav (soundfiles/sample1_1.wav) are the same utterance; the
+    C++ driver's two readers are compared on the GPU box (test_cpp_driver_sphere_input_and_htk_output)."""
+    GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    raw = open(os.path.join(GOLDEN, "sample1_sphere.wav"), "rb").read()
+    assert raw[:7] == b"NIST_1A" and int(raw[8:16]) == 1024
+    head = raw[:1024].decode("ascii", "replace")
+    assert "sample_count -i 54682" in head and "sample_byte_format -s2 01" in head
+    sph = np.frombuffer(raw[1024:1024 + 2 * 54682], dtype="<i2")
+    pcm, sr = orc.read_wav_pcm16(os.path.join(GOLDEN, "sample1_riff.wav"))
+    assert sr == 16000 and np.array_equal(pcm[:, 0], sph)

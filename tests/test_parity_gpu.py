@@ -426,6 +426,39 @@ def test_cpp_driver_text_output(orc, a0001, tmp_path):
     assert np.abs(got[:, 1:] - want).max() <= 1e-4 * np.abs(want).max() + 1e-6   # + %f quantisation
 
 
+def test_cpp_driver_sphere_input_and_htk_output(orc, tmp_path):
+    """The reference's own sample1.wav is a NIST SPHERE file (libsndfile reads it, ASR_OCL.cpp:170-175);
+    soundfiles/sample1_1.wav holds the same 54682 samples as RIFF.  The driver must read both to the
+    same features, and its HTK binary output (big-endian header + float32 rows; the reference's binary
+    branch is a stub, ASR_OCL.cpp:315-319) must hold the floats the text rows print."""
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "asr-featext-opencl_amd", "host", "afet_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    opts = ["--banks", "26", "--ceps", "13", "--c0", "1", "--norm", "0", "--dyn", "2", "--l1", "3", "--l2", "3",
+            "--sample-limit", "20000"]
+    sph, riff = os.path.join(GOLDEN, "sample1_sphere.wav"), os.path.join(GOLDEN, "sample1_riff.wav")
+    t_s, t_r, h_s = tmp_path / "s.txt", tmp_path / "r.txt", tmp_path / "s.htk"
+    subprocess.check_call([exe] + opts + [sph, str(t_s), riff, str(t_r)])
+    subprocess.check_call([exe] + opts + ["--htk", sph, str(h_s)])
+    assert open(t_s).read() == open(t_r).read()
+    rows = np.array([[float(v) for v in line.strip().strip("|").split("|")] for line in open(t_s)])
+    pcm, sr = orc.read_wav_pcm16(riff)
+    pcm = pcm[:, 0].copy()
+    assert pcm.size == 54682 and sr == 16000
+    want = orc.run_utterance(orc.make_config(20000, num_banks=26, ceps_len=13, want_c0=True), pcm)
+    assert rows.shape == (want.shape[0], 1 + 42)
+    assert np.abs(rows[:, 1:] - want).max() <= 1e-4 * np.abs(want).max() + 1e-6
+    raw = open(h_s, "rb").read()
+    n, period, size, kind = struct.unpack(">iihh", raw[:12])
+    assert (n, period, size) == (want.shape[0], 100000, 4 * 42)
+    assert kind & 0xFFFF == 6 | 0x2000 | 0x0100 | 0x0200          # MFCC_0_D_A
+    htk = np.frombuffer(raw[12:], dtype=">f4").reshape(n, 42)
+    assert np.abs(htk - rows[:, 1:]).max() <= 5.1e-7 * max(1.0, np.abs(htk).max()) + 5e-7   # %f rounding
+
+
 def test_bench_two_rank_launch_path(tmp_path):
     """bench.py's N>1 path (one process per rank under torch.distributed.run, barrier, max over ranks,
     whole-job aggregate) rehearsed with 2 ranks on this box's single GPU: gloo instead of RCCL, both
