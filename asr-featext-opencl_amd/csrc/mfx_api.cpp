@@ -93,6 +93,13 @@ struct mfx_handle {
     int n_chunks_stream_max = 0;
     int16_t *h_stage = nullptr; // pinned
     size_t h_stage_n = 0;
+    // VTLN sweep (mfx_apply_alphas): one filterbank, one static and one output block per alpha
+    std::vector<float> sweep_alphas;      // alphas of the tables currently in d_sweep_w
+    int sweep_cap = 0;                    // alphas the sweep buffers hold
+    int sweep_n = 0;                      // alphas of the last sweep (0: last apply was a plain one)
+    DevBuf<float> d_sweep_w, d_sweep_src, d_sweep_blk, d_sweep_stats;
+    DevBuf<int32_t> d_sweep_beg;
+    DevBuf<Segment> d_sweep_segs;         // [2][sweep_cap]: rows with context, rows delivered
 
     // batch plan
     int32_t n_utt = 0;
@@ -329,6 +336,12 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_src.release();
     h->d_blk.release();
     h->d_stats_stream.release();
+    h->d_sweep_w.release();
+    h->d_sweep_beg.release();
+    h->d_sweep_src.release();
+    h->d_sweep_blk.release();
+    h->d_sweep_stats.release();
+    h->d_sweep_segs.release();
     h->d_chunks_stream.release();
     h->d_chunks.release();
     h->d_segs.release();
@@ -698,9 +711,47 @@ extern "C" int mfx_flush(mfx_handle *h, int32_t *frames_out)
     return MFX_OK;
 }
 
-extern "C" int mfx_apply(mfx_handle *h)
+namespace {
+
+// (Re)build the filterbanks of a sweep and size its buffers.
+int prepare_sweep(mfx_handle *h, const float *alphas, int n)
 {
-    if (!h) return MFX_ERR_ARG;
+    const size_t wstride = (size_t)2 * h->W2, bstride = (size_t)h->nb + 2;
+    const bool same = (int)h->sweep_alphas.size() == n && std::equal(alphas, alphas + n, h->sweep_alphas.begin());
+    if (n > h->sweep_cap) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, h->d_sweep_w.alloc(wstride * n));
+        HIP_TRY(h, h->d_sweep_beg.alloc(bstride * n));
+        HIP_TRY(h, h->d_sweep_src.alloc((size_t)n * h->cap_rows * h->cols));
+        HIP_TRY(h, h->d_sweep_blk.alloc((size_t)n * h->cap_rows * h->width));
+        HIP_TRY(h, h->d_sweep_stats.alloc((size_t)3 * n * 2 * h->cols));
+        HIP_TRY(h, hipMemset(h->d_sweep_stats.p, 0, (size_t)3 * n * 2 * h->cols * sizeof(float)));
+        HIP_TRY(h, h->d_sweep_segs.alloc((size_t)2 * n));
+        h->sweep_cap = n;
+    }
+    if (same && n <= h->sweep_cap && !h->sweep_alphas.empty()) return MFX_OK;
+    std::vector<float> w(wstride * n);
+    std::vector<int32_t> b(bstride * n);
+    for (int a = 0; a < n; ++a) {
+        MelTable t;
+        build_mel_table(h->nb, h->W2, h->cfg.sample_rate, h->cfg.low_freq, h->cfg.high_freq, alphas[a], t);
+        for (int v : t.beg)
+            if (v < 0 || v > h->W2 / 2) return fail(h, MFX_ERR_CONFIG, "mel filter edge outside [0, fft_size/2]");
+        std::copy(t.weights.begin(), t.weights.end(), w.begin() + wstride * a);
+        std::copy(t.beg.begin(), t.beg.end(), b.begin() + bstride * a);
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(h->d_sweep_w.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_sweep_beg.p, b.data(), b.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->sweep_alphas.assign(alphas, alphas + n);
+    return MFX_OK;
+}
+
+// apply() for the current block: n_alpha == 0 -> the handle's alpha into d_src/d_blk (ParamBase::apply);
+// n_alpha >= 1 -> every alpha of the list from the same stored spectrum, alpha a into block a of
+// d_sweep_src/d_sweep_blk (the reference's alpha loop ASR_OCL.cpp:236-243 as one launch per stage).
+int apply_impl(mfx_handle *h, const float *alphas, int n_alpha)
+{
     HIP_TRY(h, hipSetDevice(h->device));
     const int D = h->D;
     int wcnd, wc;
@@ -724,8 +775,13 @@ extern "C" int mfx_apply(mfx_handle *h)
     }
     if (wcnd > h->cap_rows) return fail(h, MFX_ERR_WINDOW_HIGH, kMsgHigh);
 
-    int rc = refresh_mel(h);
+    const bool sweep = n_alpha > 0;
+    const int n_tab = sweep ? n_alpha : 1;
+    int rc = sweep ? prepare_sweep(h, alphas, n_alpha) : refresh_mel(h);
     if (rc != MFX_OK) return rc;
+    float *d_src = sweep ? h->d_sweep_src.p : h->d_src.p;
+    float *d_blk = sweep ? h->d_sweep_blk.p : h->d_blk.p;
+    float *d_stats = sweep ? h->d_sweep_stats.p : h->d_stats_stream.p;
 
     // filterbank + log + DCT over all frames with context
     MelcepParams mp;
@@ -733,26 +789,20 @@ extern "C" int mfx_apply(mfx_handle *h)
     mp.spec = h->d_spec.p;
     mp.spec_pitch = h->spec_pitch;
     mp.n_rows = wcnd;
-    mp.feat = h->d_src.p;
+    mp.feat = d_src;
     mp.feat_pitch = h->cols;
     mp.fft_size = h->W2;
-    mp.mel_w = h->d_mel_w.p;
-    mp.mel_beg = h->d_mel_beg.p;
+    mp.mel_w = sweep ? h->d_sweep_w.p : h->d_mel_w.p;
+    mp.mel_beg = sweep ? h->d_sweep_beg.p : h->d_mel_beg.p;
     mp.dct = h->ceps > 0 ? h->d_dct.p : nullptr;
     mp.num_banks = h->nb;
     mp.dct_len = h->dl;
     mp.cols = h->cols;
+    mp.n_tables = n_tab;
+    mp.mel_w_stride = (int64_t)2 * h->W2;
+    mp.mel_beg_stride = h->nb + 2;
+    mp.feat_table_stride = (int64_t)h->cap_rows * h->cols;
     HIP_TRY(h, launch_melcep(mp, h->stream));
-
-    const bool norm = h->cfg.norm != MFX_NORM_NONE;
-    Segment sg;
-    std::memset(&sg, 0, sizeof(sg));
-    if (norm && !h->cfg.norm_after_dyn) { // normalise statics (with context) before the deltas
-        sg.out_row0 = 0;
-        sg.n_out = wcnd;
-        rc = run_norm(h, h->d_src.p, h->cols, 0, nullptr, 1, &sg, 0, h->d_stats_stream.p, use_last);
-        if (rc != MFX_OK) return rc;
-    }
 
     // static row offset as the reference reads it (mfcccpu.cpp:274,439): was_flushed() ? 0 : D.
     // With bug_compat off a flush block always reads at D (fixes B1).
@@ -760,51 +810,103 @@ extern "C" int mfx_apply(mfx_handle *h)
     if (!h->cfg.bug_compat && h->last_block) at_zero = false;
     const int static_off = at_zero ? 0 : D;
 
+    Segment sg; // rows with context (statics), used by the normalisation before the deltas
+    std::memset(&sg, 0, sizeof(sg));
+    sg.n_out = wcnd;
+    Segment sd; // the block's delivered rows
+    std::memset(&sd, 0, sizeof(sd));
+    sd.n_out = wc;
+    sd.static_off = static_off;
+    if (first) { // D replicated rows in front (mfcccpu.cpp:243-248)
+        sd.shift = -D;
+        sd.lo = 0;
+        sd.hi = wcnd - 1;
+    } else if (last) { // D replicated rows behind (mfcccpu.cpp:249-254)
+        sd.shift = 0;
+        sd.lo = 0;
+        sd.hi = wc + D - 1;
+    } else {
+        sd.shift = 0;
+        sd.lo = 0;
+        sd.hi = wcnd - 1;
+    }
+    const Segment *segs_ctx = nullptr, *segs_out = nullptr;
+    if (sweep) { // one segment per alpha: block a of the sweep buffers
+        std::vector<Segment> hs((size_t)2 * n_alpha);
+        for (int a = 0; a < n_alpha; ++a) {
+            hs[a] = sg;
+            hs[a].src_row0 = hs[a].out_row0 = (int64_t)a * h->cap_rows;
+            hs[n_alpha + a] = sd;
+            hs[n_alpha + a].src_row0 = hs[n_alpha + a].out_row0 = (int64_t)a * h->cap_rows;
+        }
+        HIP_TRY(h, hipMemcpyAsync(h->d_sweep_segs.p, hs.data(), hs.size() * sizeof(Segment), hipMemcpyHostToDevice,
+                                  h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream)); // hs is a local
+        segs_ctx = h->d_sweep_segs.p;
+        segs_out = h->d_sweep_segs.p + n_alpha;
+    }
+
+    const bool norm = h->cfg.norm != MFX_NORM_NONE;
+    if (norm && !h->cfg.norm_after_dyn) { // normalise statics (with context) before the deltas
+        rc = run_norm(h, d_src, h->cols, 0, segs_ctx, n_tab, sweep ? nullptr : &sg, 0, d_stats, use_last);
+        if (rc != MFX_OK) return rc;
+    }
+
     DeltaParams dp;
     std::memset(&dp, 0, sizeof(dp));
-    dp.src = h->d_src.p;
+    dp.src = d_src;
     dp.src_pitch = h->cols;
-    dp.out = h->d_blk.p;
+    dp.out = d_blk;
     dp.out_pitch = h->width;
-    dp.n_segs = 1;
+    dp.segs = segs_out;
+    dp.n_segs = n_tab;
     dp.cols = h->cols;
     dp.l1 = h->l1;
     dp.l2 = h->l2;
     dp.tiles_per_seg_max = (wc + 63) / 64;
-    dp.inline_seg = 1;
-    sg.src_row0 = 0;
-    sg.out_row0 = 0;
-    sg.n_out = wc;
-    sg.static_off = static_off;
-    if (first) { // D replicated rows in front (mfcccpu.cpp:243-248)
-        sg.shift = -D;
-        sg.lo = 0;
-        sg.hi = wcnd - 1;
-    } else if (last) { // D replicated rows behind (mfcccpu.cpp:249-254)
-        sg.shift = 0;
-        sg.lo = 0;
-        sg.hi = wc + D - 1;
-    } else {
-        sg.shift = 0;
-        sg.lo = 0;
-        sg.hi = wcnd - 1;
-    }
-    dp.seg0 = sg;
+    dp.inline_seg = sweep ? 0 : 1;
+    dp.seg0 = sd;
     HIP_TRY(h, launch_delta(dp, h->stream));
 
     if (norm && h->cfg.norm_after_dyn) {
-        Segment so;
-        std::memset(&so, 0, sizeof(so));
-        so.out_row0 = 0;
-        so.n_out = wc;
         const int groups = h->width / h->cols;
         for (int g = 0; g < groups; ++g) {
-            rc = run_norm(h, h->d_blk.p, h->width, g * h->cols, nullptr, 1, &so, 0,
-                          h->d_stats_stream.p + (size_t)g * 2 * h->cols, use_last);
+            rc = run_norm(h, d_blk, h->width, g * h->cols, segs_out, n_tab, sweep ? nullptr : &sd, 0,
+                          d_stats + (size_t)g * n_tab * 2 * h->cols, use_last);
             if (rc != MFX_OK) return rc;
         }
     }
     h->block_applied = true;
+    h->sweep_n = sweep ? n_alpha : 0;
+    return MFX_OK;
+}
+
+} // namespace
+
+extern "C" int mfx_apply(mfx_handle *h)
+{
+    if (!h) return MFX_ERR_ARG;
+    return apply_impl(h, nullptr, 0);
+}
+
+extern "C" int mfx_apply_alphas(mfx_handle *h, const float *alphas, int32_t n_alpha)
+{
+    if (!h || !alphas || n_alpha < 1 || n_alpha > 4096) return MFX_ERR_ARG;
+    for (int a = 0; a < n_alpha; ++a)
+        if (!(alphas[a] > 0.f)) return fail(h, MFX_ERR_ARG, "alpha must be positive");
+    return apply_impl(h, alphas, n_alpha);
+}
+
+extern "C" int mfx_get_output_data_alpha(mfx_handle *h, int32_t alpha_index, float *data_out, int32_t frames)
+{
+    if (!h || (!data_out && frames > 0) || frames < 0) return MFX_ERR_ARG;
+    if (alpha_index < 0 || alpha_index >= h->sweep_n) return fail(h, MFX_ERR_ARG, "alpha index outside the last sweep");
+    if (frames > h->cap_rows) return fail(h, MFX_ERR_WINDOW_HIGH, kMsgHigh);
+    if (frames == 0) return MFX_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(data_out, h->d_sweep_blk.p + (size_t)alpha_index * h->cap_rows * h->width,
+                              sizeof(float) * (size_t)frames * h->width, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return MFX_OK;
 }
 

@@ -85,6 +85,12 @@ struct MelcepParams {
     const int32_t *mel_beg;
     const float *dct;
     int32_t num_banks, dct_len, cols;
+    // VTLN sweep: n_tables (>= 1) warped filterbanks over the same spectrum in one launch; table a is
+    // mel_w + a * mel_w_stride / mel_beg + a * mel_beg_stride and writes feat + a * feat_table_stride
+    int32_t n_tables;
+    int32_t mel_beg_stride;
+    int64_t mel_w_stride;
+    int64_t feat_table_stride;
 };
 
 struct DeltaParams {

@@ -766,11 +766,15 @@ __global__ void __launch_bounds__(256) k_melcep(MelcepParams p)
     float *s_mag = s_dct + dct_pad + wave * (bins_pad + nb_pad);
     float *s_mel = s_mag + bins_pad;
 
+    // blockIdx.y = filterbank of a VTLN sweep (one table per alpha over the same spectrum)
+    const float *mel_w = p.mel_w + (int64_t)blockIdx.y * p.mel_w_stride;
+    const int32_t *mel_beg = p.mel_beg + (int64_t)blockIdx.y * p.mel_beg_stride;
+    float *feat = p.feat + (int64_t)blockIdx.y * p.feat_table_stride;
     for (int i = tid; i < nbins; i += 256) {
-        s_w0[i] = p.mel_w[i];
-        s_w1[i] = p.mel_w[W2 + i];
+        s_w0[i] = mel_w[i];
+        s_w1[i] = mel_w[W2 + i];
     }
-    for (int i = tid; i < nb + 2; i += 256) s_beg[i] = p.mel_beg[i];
+    for (int i = tid; i < nb + 2; i += 256) s_beg[i] = mel_beg[i];
     for (int i = tid; i < dct_floats; i += 256) s_dct[i] = p.dct[i];
     __syncthreads();
 
@@ -779,7 +783,7 @@ __global__ void __launch_bounds__(256) k_melcep(MelcepParams p)
         for (int k = lane; k < nbins; k += 64) s_mag[k] = src[k];
         wave_sync();
         mel_log_dct<64>(s_mag, s_mel, lane, s_w0, s_w1, s_beg, p.dct ? s_dct : nullptr, nb, dl, p.cols,
-                        p.feat + r * p.feat_pitch);
+                        feat + r * p.feat_pitch);
         wave_sync();
     }
 }
@@ -1091,7 +1095,9 @@ hipError_t launch_melcep(const MelcepParams &p, hipStream_t stream)
     int64_t blocks = (p.n_rows + 3) / 4;
     const int cap = num_cus() * 8;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(k_melcep, dim3((unsigned)blocks), dim3(256), lds, stream, p);
+    const int tables = p.n_tables > 1 ? p.n_tables : 1;
+    if (tables > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_melcep, dim3((unsigned)blocks, (unsigned)tables), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 

@@ -148,7 +148,7 @@ void write_rows(FILE *out, const float *rows, int n, int width, int first_frame,
     }
 }
 
-void process_file(ParamBase &param, const Options &o, const std::string &in, const std::string &out_name,
+void process_file(MfccHip &param, const Options &o, const std::string &in, const std::string &out_name,
                   float sample_rate)
 {
     Wav w = read_wav(in);
@@ -176,32 +176,36 @@ void process_file(ParamBase &param, const Options &o, const std::string &in, con
     }
     size_t pos = 0;
     int total = 0;
+    std::vector<float> alphas;
+    for (auto &oa : outs) alphas.push_back(oa.first);
+    // One alpha: the reference's set_alpha + apply + get_output_data (ASR_OCL.cpp:236-243).  Several:
+    // the whole sweep over the block's stored spectrum in one call (mfx_apply_alphas).
+    auto emit = [&](int n) {
+        if (n <= 0) return;
+        if (alphas.size() > 1) param.apply_alphas(alphas.data(), (int)alphas.size());
+        for (size_t i = 0; i < outs.size(); ++i) {
+            if (alphas.size() > 1) {
+                param.get_output_data_alpha((int)i, rows.data(), n);
+            } else {
+                param.set_alpha(alphas[i]);
+                param.apply();
+                param.get_output_data(rows.data(), n);
+            }
+            if (o.htk)
+                write_rows_htk(outs[i].second, rows.data(), n, width);
+            else
+                write_rows(outs[i].second, rows.data(), n, width, total, t0, dt);
+        }
+    };
     while (pos < mono.size()) {
         const int n_in = (int)std::min<size_t>(mono.size() - pos, (size_t)limit);
         const int n = param.set_input(mono.data() + pos, n_in);
-        for (auto &oa : outs) {
-            param.set_alpha(oa.first);
-            param.apply();
-            param.get_output_data(rows.data(), n);
-            if (o.htk)
-                write_rows_htk(oa.second, rows.data(), n, width);
-            else
-                write_rows(oa.second, rows.data(), n, width, total, t0, dt);
-        }
+        emit(n);
         total += n;
         pos += n_in;
     }
     const int n = param.flush();
-    if (n > 0)
-        for (auto &oa : outs) {
-            param.set_alpha(oa.first);
-            param.apply();
-            param.get_output_data(rows.data(), n);
-            if (o.htk)
-                write_rows_htk(oa.second, rows.data(), n, width);
-            else
-                write_rows(oa.second, rows.data(), n, width, total, t0, dt);
-        }
+    if (n > 0) emit(n);
     total += n;
     for (auto &oa : outs) {
         if (o.htk) {

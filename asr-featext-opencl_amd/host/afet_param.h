@@ -86,6 +86,11 @@ public:
     void apply() override;
     void get_output_data(float *data_out, int window_count) override;
 
+    // VTLN sweep over the current block's spectrum (the caller's alpha loop, ASR_OCL.cpp:236-243, in
+    // one call); block i of the result is read with get_output_data_alpha(i, ...)
+    void apply_alphas(const float *alphas, int n_alpha);
+    void get_output_data_alpha(int alpha_index, float *data_out, int window_count);
+
     // upper bound on the rows one set_input()/flush() can deliver (the reference's own bound,
     // estimated_window_count(get_input_buffer_size()), can be exceeded: SURVEY B6)
     int max_frames_out() const;

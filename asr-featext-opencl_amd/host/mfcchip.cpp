@@ -112,4 +112,11 @@ void MfccHip::get_output_data(float *data_out, int window_count)
     check(mfx_get_output_data(m_handle, data_out, window_count));
 }
 
+void MfccHip::apply_alphas(const float *alphas, int n_alpha) { check(mfx_apply_alphas(m_handle, alphas, n_alpha)); }
+
+void MfccHip::get_output_data_alpha(int alpha_index, float *data_out, int window_count)
+{
+    check(mfx_get_output_data_alpha(m_handle, alpha_index, data_out, window_count));
+}
+
 int MfccHip::max_frames_out() const { return mfx_max_frames_out(m_handle); }

@@ -53,6 +53,7 @@ EXPORTED_SYMBOLS = (
     "mfx_create", "mfx_destroy", "mfx_last_error", "mfx_status_string", "mfx_abi_version",
     "mfx_set_window", "mfx_set_input", "mfx_flush", "mfx_set_alpha", "mfx_apply",
     "mfx_get_output_data_width", "mfx_get_output_data", "mfx_get_input_buffer_size",
+    "mfx_apply_alphas", "mfx_get_output_data_alpha",
     "mfx_estimated_window_count", "mfx_max_frames_out", "mfx_fft_size",
     "mfx_batch_frames", "mfx_batch_plan", "mfx_batch_run_device", "mfx_batch_run_host", "mfx_batch_overlap",
     "mfx_set_stream", "mfx_synchronize", "mfx_profile_enable", "mfx_profile_read",
@@ -101,6 +102,8 @@ def load_library():
     L.mfx_apply.argtypes = [vp]
     L.mfx_get_output_data_width.argtypes = [vp]
     L.mfx_get_output_data.argtypes = [vp, fp, i32]
+    L.mfx_apply_alphas.argtypes = [vp, fp, i32]
+    L.mfx_get_output_data_alpha.argtypes = [vp, i32, fp, i32]
     L.mfx_get_input_buffer_size.argtypes = [vp]
     L.mfx_estimated_window_count.argtypes = [vp, i32]
     L.mfx_max_frames_out.argtypes = [vp]
@@ -233,6 +236,18 @@ class MfccHip:
     def get_output_data(self, window_count):
         out = np.empty((max(int(window_count), 0), self.get_output_data_width()), dtype=np.float32)
         self._chk(self._L.mfx_get_output_data(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), int(window_count)))
+        return out
+
+    def apply_alphas(self, alphas):
+        """VTLN sweep: every warp factor of `alphas` over the stored spectrum of the current block in
+        one call (the reference's alpha loop, ASR_OCL.cpp:236-243)."""
+        a = np.ascontiguousarray(alphas, dtype=np.float32)
+        self._chk(self._L.mfx_apply_alphas(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), int(a.size)))
+
+    def get_output_data_alpha(self, alpha_index, window_count):
+        out = np.empty((max(int(window_count), 0), self.get_output_data_width()), dtype=np.float32)
+        self._chk(self._L.mfx_get_output_data_alpha(self._h, int(alpha_index), out.ctypes.data_as(C.POINTER(C.c_float)),
+                                                    int(window_count)))
         return out
 
     # -- extensions ---------------------------------------------------------------------------------

@@ -106,6 +106,14 @@ int mfx_get_output_data_width(const mfx_handle *h);
 /* ParamBase::get_output_data (parambase.h:32; mfccopencl.cpp:551-569): `frames` rows of
  * get_output_data_width() floats, row-major [static | delta | delta-delta]. */
 int mfx_get_output_data(mfx_handle *h, float *data_out, int32_t frames);
+/* VTLN sweep: the reference's alpha loop (ASR_OCL.cpp:236-243: one set_input, then set_alpha + apply +
+ * get_output_data per warp factor; warp mfcccpu.cpp:36-38) as ONE call.  All n_alpha warped filterbanks
+ * are applied to the stored spectrum of the current block in one launch per stage; results are the
+ * same as n_alpha rounds of mfx_set_alpha + mfx_apply.  Read block a with mfx_get_output_data_alpha.
+ * The handle's own alpha (mfx_set_alpha) is not changed.  Normalisation statistics are kept per
+ * alpha, so a flush block re-uses the statistics of the same alpha (normalizercpu.cpp use_last_stats). */
+int mfx_apply_alphas(mfx_handle *h, const float *alphas, int32_t n_alpha);
+int mfx_get_output_data_alpha(mfx_handle *h, int32_t alpha_index, float *data_out, int32_t frames);
 /* ParamBase::get_input_buffer_size / estimated_window_count (parambase.h:23-24, parambase.cpp:12-19) */
 int mfx_get_input_buffer_size(const mfx_handle *h);
 int mfx_estimated_window_count(const mfx_handle *h, int32_t samples);

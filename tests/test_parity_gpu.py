@@ -257,6 +257,59 @@ def test_vtln_alpha_sweep_on_one_fft(pkg, orc, alpha):
     assert np.array_equal(m.debug_read(1), o.tables()["filter_beg"])
 
 
+@pytest.mark.parametrize("norm,nad", [(0, True), (2, True), (1, False)])
+def test_vtln_sweep_in_one_call(pkg, orc, norm, nad):
+    """mfx_apply_alphas: the reference's alpha loop (ASR_OCL.cpp:236-243) as one call per block, all
+    warped filterbanks over the stored spectrum in one launch per stage.  Streamed in several blocks
+    plus flush; every alpha's rows must equal the oracle run with that alpha alone and be bit-identical
+    to set_alpha + apply + get_output_data on the same handle."""
+    alphas = [0.88, 1.0, 1.12, 0.94]
+    pcm = synth_utterance(41000, 17)
+    m, cfg, w = make_pair(pkg, orc, 20000, norm=norm, nad=nad)
+    got = [[] for _ in alphas]
+    ref_same_handle = [[] for _ in alphas]
+
+    def emit(n):
+        if n <= 0:
+            return
+        m.apply_alphas(alphas)
+        for i in range(len(alphas)):
+            got[i].append(m.get_output_data_alpha(i, n))
+        if norm == 0:       # with normalisation the per-alpha loop shares one statistics slot (header note)
+            for i, a in enumerate(alphas):
+                m.set_alpha(a)
+                m.apply()
+                ref_same_handle[i].append(m.get_output_data(n))
+
+    for pos in range(0, pcm.size, 16000):
+        emit(m.set_input(pcm[pos:pos + 16000]))
+    emit(m.flush())
+    for i, a in enumerate(alphas):
+        o = orc.OracleMfcc(cfg, w)
+        rows = []
+        for pos in range(0, pcm.size, 16000):
+            n = o.set_input(pcm[pos:pos + 16000])
+            if n > 0:
+                o.set_alpha(a)
+                o.apply()
+                rows.append(o.get_output_data(n))
+        n = o.flush()
+        if n > 0:
+            o.set_alpha(a)
+            o.apply()
+            rows.append(o.get_output_data(n))
+        want = np.concatenate(rows)
+        g = np.concatenate(got[i])
+        assert g.shape == want.shape
+        if norm == 0:
+            assert_close(g, want, "sweep alpha %.2f" % a, groups=3)
+            assert np.array_equal(g, np.concatenate(ref_same_handle[i]))
+        else:
+            assert_close(g, want, "sweep alpha %.2f norm %d" % (a, norm), tol_max=1e-3, tol_l2=2e-4, groups=3)
+    with pytest.raises(Exception):
+        m.get_output_data_alpha(len(alphas), 1)
+
+
 def test_c3_shape_1024_override(pkg, orc):
     """BASELINE configs[2] in small: 25 ms window zero padded to a 1024-point FFT, 80 mel, 13 MFCC."""
     pcm = synth_utterance(60000, 9)
@@ -457,6 +510,42 @@ def test_cpp_driver_sphere_input_and_htk_output(orc, tmp_path):
     assert kind & 0xFFFF == 6 | 0x2000 | 0x0100 | 0x0200          # MFCC_0_D_A
     htk = np.frombuffer(raw[12:], dtype=">f4").reshape(n, 42)
     assert np.abs(htk - rows[:, 1:]).max() <= 5.1e-7 * max(1.0, np.abs(htk).max()) + 5e-7   # %f rounding
+
+
+def test_cpp_driver_alpha_range_uses_the_sweep(orc, a0001, tmp_path):
+    """--alpha-min/--alpha-max/--alpha-step (the reference's option table, ASR_OCL.cpp:569-669): one output
+    file per warp factor, written from MfccHip::apply_alphas; each must match the oracle at that alpha."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "asr-featext-opencl_amd", "host", "afet_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    out = tmp_path / "v.txt"
+    subprocess.check_call([exe, "--banks", "26", "--ceps", "13", "--c0", "0", "--norm", "0", "--dyn", "2", "--l1", "3",
+                           "--l2", "3", "--sample-limit", "48000", "--alpha-min", "0.9", "--alpha-max", "1.15",
+                           "--alpha-step", "0.1", os.path.join(GOLDEN, "a0001.wav"), str(out)])
+    names = sorted(p.name for p in tmp_path.iterdir())
+    assert names == ["v.txt.0.900000", "v.txt.1.000000", "v.txt.1.100000"]
+    cfg = orc.make_config(48000, num_banks=26, ceps_len=13)
+    for name, alpha in zip(names, (np.float32(0.9), np.float32(0.9) + np.float32(0.1), np.float32(0.9) + 2 * np.float32(0.1))):
+        got = np.array([[float(v) for v in line.strip().strip("|").split("|")] for line in open(tmp_path / name)])
+        o = orc.OracleMfcc(cfg, orc.reference_window(400))
+        rows = []
+        blk = o.input_buffer_size                      # the driver's block size (47920)
+        for pos in range(0, a0001.size, blk):
+            n = o.set_input(a0001[pos:pos + blk])
+            if n > 0:
+                o.set_alpha(float(alpha))
+                o.apply()
+                rows.append(o.get_output_data(n))
+        n = o.flush()
+        if n > 0:
+            o.set_alpha(float(alpha))
+            o.apply()
+            rows.append(o.get_output_data(n))
+        want = np.concatenate(rows)
+        assert got.shape == (711, 40)
+        assert np.abs(got[:, 1:] - want).max() <= 1e-4 * np.abs(want).max() + 1e-6
 
 
 def test_bench_two_rank_launch_path(tmp_path):
