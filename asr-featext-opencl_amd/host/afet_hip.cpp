@@ -12,8 +12,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "afet_param.h"
@@ -29,6 +32,7 @@ struct Options {
     int sample_limit = 10000000, device = 0;
     bool bug_compat = true;
     bool htk = false; // binary output in HTK parameter-file format instead of the reference's text rows
+    std::vector<int> devices; // --devs a,b,...: one worker (own MfccHip, own thread) per entry
 };
 
 struct Wav {
@@ -214,7 +218,41 @@ void process_file(MfccHip &param, const Options &o, const std::string &in, const
         }
         std::fclose(oa.second);
     }
+    static std::mutex print_lock;
+    std::lock_guard<std::mutex> g(print_lock);
     std::printf("%s: %d frames x %d\n", in.c_str(), total, width);
+}
+
+// One worker of the reference's file queue (process_files_worker over the shared std::list,
+// ASR_OCL.cpp:109-338,340-368): its own extractor on its own device, files drawn from a shared index
+// until the queue is empty.  The reference runs its workers one after another (:365-366); these run
+// concurrently, one per GPU (utterances are independent: SURVEY 8e, no exchange between devices).
+void worker(const Options &o, int device, float sr, const std::vector<std::string> &files,
+            std::atomic<size_t> &next, std::atomic<int> &failures)
+{
+    try {
+        const long W = (long)(sr * o.window_ms * 1e-3), S = (long)(sr * o.shift_ms * 1e-3);
+        MfccHip param(o.sample_limit, (int)W, (int)S, o.banks, sr, o.low, o.high, o.ceps, o.c0, o.lift,
+                      (Normalizer::norm_t)o.norm, (ParamBase::dyn_t)o.dyn, o.l1, o.l2, o.norm_after_dyn, device,
+                      o.bug_compat);
+        std::vector<float> window((size_t)W);
+        for (long i = 0; i < W; ++i) // ASR_OCL.cpp:149-151
+            window[i] = (float)(0.56f - 0.46f * std::cos((2.0f * M_PI * i) / W)) / 32768.f;
+        param.set_window(window.data());
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (2 * i + 1 >= files.size()) break;
+            try {
+                process_file(param, o, files[2 * i], files[2 * i + 1], sr);
+            } catch (const std::exception &e) { // a bad file does not stop the queue
+                std::fprintf(stderr, "Exception caught %s\n", e.what());
+                ++failures;
+            }
+        }
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "Exception caught %s\n", e.what());
+        ++failures;
+    }
 }
 
 } // namespace
@@ -251,13 +289,21 @@ int main(int argc, char **argv)
         else if (a == "--alpha-step") o.alpha_step = (float)std::atof(val());
         else if (a == "--sample-limit") o.sample_limit = std::atoi(val());
         else if (a == "--dev") o.device = std::atoi(val());
+        else if (a == "--devs") { // comma separated device list; an id may repeat (two workers on one GPU)
+            for (const char *q = val(); *q;) {
+                o.devices.push_back((int)std::strtol(q, const_cast<char **>(&q), 10));
+                if (*q == ',') ++q;
+                else if (*q) { std::fprintf(stderr, "bad --devs list\n"); return 2; }
+            }
+        }
         else if (a == "--bug-compat") o.bug_compat = std::atoi(val()) != 0;
         else if (a == "--htk") o.htk = true;
         else if (a == "--help") {
             std::printf("afet_hip [--window-size ms] [--shift ms] [--banks n] [--ceps n] [--c0 0|1] [--norm 0..3]\n"
                         "         [--dyn 0..2] [--l1 n] [--l2 n] [--low-freq hz] [--high-freq hz] [--lift-coef x]\n"
                         "         [--norm-after-dyn 0|1] [--alpha a | --alpha-min a --alpha-max b --alpha-step s]\n"
-                        "         [--sample-limit n] [--dev n] [--bug-compat 0|1] [--htk]  in.wav out.txt [...]\n"
+                        "         [--sample-limit n] [--dev n | --devs a,b,...] [--bug-compat 0|1] [--htk]  in.wav out.txt [...]\n"
+                        "  --devs: one worker per listed GPU, files dealt from a shared queue\n"
                         "  inputs: RIFF/WAVE or NIST SPHERE, 16-bit PCM; output: the reference's text rows, or HTK binary\n");
             return 0;
         } else files.push_back(a);
@@ -269,19 +315,20 @@ int main(int argc, char **argv)
     try {
         const Wav first = read_wav(files[0]); // sample rate from the first file (ASR_OCL.cpp:342-358)
         const float sr = (float)first.sample_rate;
-        const long W = (long)(sr * o.window_ms * 1e-3), S = (long)(sr * o.shift_ms * 1e-3);
         if (o.high <= 0) o.high = sr / 2;
-        MfccHip param(o.sample_limit, (int)W, (int)S, o.banks, sr, o.low, o.high, o.ceps, o.c0, o.lift,
-                      (Normalizer::norm_t)o.norm, (ParamBase::dyn_t)o.dyn, o.l1, o.l2, o.norm_after_dyn, o.device,
-                      o.bug_compat);
-        std::vector<float> window((size_t)W);
-        for (long i = 0; i < W; ++i) // ASR_OCL.cpp:149-151
-            window[i] = (float)(0.56f - 0.46f * std::cos((2.0f * M_PI * i) / W)) / 32768.f;
-        param.set_window(window.data());
-        for (size_t i = 0; i < files.size(); i += 2) process_file(param, o, files[i], files[i + 1], sr);
+        if (o.devices.empty()) o.devices.push_back(o.device);
+        std::atomic<size_t> next{0};
+        std::atomic<int> failures{0};
+        if (o.devices.size() == 1) {
+            worker(o, o.devices[0], sr, files, next, failures);
+        } else {
+            std::vector<std::thread> pool;
+            for (int d : o.devices) pool.emplace_back(worker, std::cref(o), d, sr, std::cref(files), std::ref(next), std::ref(failures));
+            for (auto &t : pool) t.join();
+        }
+        return failures.load() ? 1 : 0;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "Exception caught %s\n", e.what());
         return 1;
     }
-    return 0;
 }

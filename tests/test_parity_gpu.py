@@ -548,6 +548,41 @@ def test_cpp_driver_alpha_range_uses_the_sweep(orc, a0001, tmp_path):
         assert np.abs(got[:, 1:] - want).max() <= 1e-4 * np.abs(want).max() + 1e-6
 
 
+def test_cpp_driver_file_queue_workers(tmp_path):
+    """--devs: the reference's file queue (ASR_OCL.cpp:340-368) with one worker thread + one extractor per
+    listed GPU.  Rehearsed with three workers on this box's single GPU: independent handles on different
+    threads must not disturb each other (SURVEY 8b threading), so every output file must be byte-identical
+    to the one-worker run; a bad file is reported and does not stop the queue."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "asr-featext-opencl_amd", "host", "afet_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    srcs = ["a0001.wav", "a1.wav", "sample1_sphere.wav", "sample1_riff.wav", "a0001.wav", "a1.wav", "a0001.wav"]
+    opts = ["--banks", "26", "--ceps", "13", "--norm", "2", "--dyn", "2", "--l1", "3", "--l2", "3",
+            "--sample-limit", "30000"]
+
+    def run(tag, extra):
+        args = []
+        for i, s_ in enumerate(srcs):
+            args += [os.path.join(GOLDEN, s_), str(tmp_path / ("%s_%d.txt" % (tag, i)))]
+        subprocess.check_call([exe] + opts + extra + args)
+        return [open(tmp_path / ("%s_%d.txt" % (tag, i))).read() for i in range(len(srcs))]
+
+    one = run("one", [])
+    three = run("three", ["--devs", "0,0,0"])
+    assert one == three and all(len(t) > 1000 for t in one)
+    assert one[0] == one[4] == one[6] and one[2] == one[3]
+    bad = tmp_path / "bad.wav"
+    bad.write_bytes(b"not audio")
+    r = subprocess.run([exe] + opts + ["--devs", "0,0", os.path.join(GOLDEN, "a1.wav"), str(tmp_path / "q0.txt"),
+                                       str(bad), str(tmp_path / "q1.txt"),
+                                       os.path.join(GOLDEN, "a1.wav"), str(tmp_path / "q2.txt")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "Exception caught" in r.stderr
+    assert open(tmp_path / "q0.txt").read() == open(tmp_path / "q2.txt").read() == one[1]
+
+
 def test_bench_two_rank_launch_path(tmp_path):
     """bench.py's N>1 path (one process per rank under torch.distributed.run, barrier, max over ranks,
     whole-job aggregate) rehearsed with 2 ranks on this box's single GPU: gloo instead of RCCL, both
