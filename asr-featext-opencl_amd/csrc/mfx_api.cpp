@@ -118,6 +118,16 @@ struct mfx_handle {
     unsigned batch_seq = 0;
     int tiles_max = 0;
     bool batch_aligned = true;
+    // fused delta stage of the 512-point kernel: per-block chunk lists (own rows + halo) and delta tiles
+    int num_cus = 256;
+    bool fuse_delta_enabled = false; // MFX_FUSE_DELTA=1 opts in to the fused delta stage (measured 1-2 % slower
+                                     // than front end + k_delta on C2; kept tested, off by default)
+    bool fuse_plan = false;
+    int f_blocks = 0, f_done_words = 0;
+    int32_t f_nchunks = 0;
+    DevBuf<Chunk> d_fchunks;
+    DevBuf<int32_t> d_blk_chunk_off, d_blk_tile_off, d_err;
+    DevBuf<DeltaTile> d_tiles;
 
     // profiling of the dominant kernel
     bool prof_on = false;
@@ -336,6 +346,11 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_src.release();
     h->d_blk.release();
     h->d_stats_stream.release();
+    h->d_fchunks.release();
+    h->d_blk_chunk_off.release();
+    h->d_blk_tile_off.release();
+    h->d_tiles.release();
+    h->d_err.release();
     h->d_sweep_w.release();
     h->d_sweep_beg.release();
     h->d_sweep_src.release();
@@ -416,6 +431,13 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
     }
     h->spec_pitch = ((h->W2 / 2 + 1) + 3) & ~3;
     h->fast512 = front512_supported(h->W2, h->W, h->nb, h->cols, h->channels);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, hip_device) == hipSuccess && prop.multiProcessorCount > 0)
+            h->num_cus = prop.multiProcessorCount;
+        const char *e = std::getenv("MFX_FUSE_DELTA");
+        if (e) h->fuse_delta_enabled = e[0] == '1';
+    }
     h->nm16 = (h->W + 31) / 32;
 
     int rc = MFX_OK;
@@ -541,6 +563,14 @@ extern "C" int mfx_synchronize(mfx_handle *h)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->stream2) HIP_TRY(h, hipStreamSynchronize(h->stream2));
     h->tail_pending[0] = h->tail_pending[1] = false;
+    if (h->d_err.p) { // the fused delta stage reports a wait that ran out (never expected) instead of hanging
+        int32_t flag = 0;
+        HIP_TRY(h, hipMemcpy(&flag, h->d_err.p, sizeof(flag), hipMemcpyDeviceToHost));
+        if (flag != 0) {
+            (void)hipMemset(h->d_err.p, 0, sizeof(flag));
+            return fail(h, MFX_ERR_DEVICE, "fused delta stage gave up waiting for its statics");
+        }
+    }
     return MFX_OK;
 }
 
@@ -933,6 +963,140 @@ extern "C" int64_t mfx_batch_frames(const mfx_handle *h, int64_t samples)
     return t > 0 ? t : 0;
 }
 
+namespace {
+
+// Plan of the fused front end + delta stage (k_front512<..., FUSE>).  The global chunk list is cut into
+// B contiguous pieces, one per block; a piece that starts or ends inside an utterance gets a halo chunk of
+// D frames on that side (both neighbours compute those statics; identical values land on the same
+// scratch rows).  The block's own rows are grouped into tiles of <= 64 rows of one utterance; each tile
+// names the block-local chunks whose statics it reads.
+int plan_fused_delta(mfx_handle *h, const std::vector<int64_t> &T_of)
+{
+    h->fuse_plan = false;
+    const size_t n = h->h_chunks.size();
+    if (!h->fuse_delta_enabled || !h->fast512 || h->l1 <= 0 || h->cols > 16 || h->ceps <= 0 || h->D > 16 || n == 0 ||
+        n > 0x3fffffff || (h->cfg.norm != MFX_NORM_NONE && !h->cfg.norm_after_dyn))
+        return MFX_OK;
+    const int D = h->D;
+    const int B = (int)std::min<size_t>((size_t)h->num_cus, (n + 14) / 15);
+    // utterance of every chunk
+    std::vector<int32_t> utt_of(n);
+    {
+        size_t c = 0;
+        for (int u = 0; u < h->n_utt; ++u) {
+            const size_t cnt = (size_t)((T_of[u] + kChunkFrames - 1) / kChunkFrames);
+            for (size_t k = 0; k < cnt; ++k) utt_of[c++] = u;
+        }
+    }
+    std::vector<Chunk> fch;
+    fch.reserve(n + 2 * (size_t)B);
+    std::vector<DeltaTile> tiles;
+    std::vector<int32_t> coff((size_t)B + 1), toff((size_t)B + 1);
+    size_t max_list = 0;
+    for (int b = 0; b < B; ++b) {
+        const size_t c0 = n * (size_t)b / B, c1 = n * (size_t)(b + 1) / B;
+        coff[b] = (int32_t)fch.size();
+        toff[b] = (int32_t)tiles.size();
+        if (c1 <= c0) continue;
+        const size_t base = fch.size();
+        {   // halo in front
+            const Chunk &f = h->h_chunks[c0];
+            const int64_t avail = f.out_row - h->utt_row[utt_of[c0]];
+            if (avail > 0) {
+                const int hal = (int)std::min<int64_t>(D, avail);
+                Chunk c;
+                c.pcm_off = f.pcm_off - (int64_t)hal * h->S;
+                c.out_row = f.out_row - hal;
+                c.n_frames = hal;
+                c.pad = 0;
+                fch.push_back(c);
+            }
+        }
+        const size_t own0 = fch.size() - base; // local index of the first own chunk
+        for (size_t c = c0; c < c1; ++c) fch.push_back(h->h_chunks[c]);
+        {   // halo behind
+            const Chunk &l = h->h_chunks[c1 - 1];
+            const int u = utt_of[c1 - 1];
+            const int64_t end_row = l.out_row + l.n_frames;
+            const int64_t avail = h->utt_row[u] + T_of[u] - end_row;
+            if (avail > 0) {
+                const int hal = (int)std::min<int64_t>(D, avail);
+                Chunk c;
+                c.pcm_off = l.pcm_off + (int64_t)l.n_frames * h->S;
+                c.out_row = end_row;
+                c.n_frames = hal;
+                c.pad = 0;
+                fch.push_back(c);
+            }
+        }
+        const size_t cnt = fch.size() - base;
+        max_list = std::max(max_list, cnt);
+        // tiles over the own chunks: runs of one utterance, <= 64 rows each
+        auto local_of_row = [&](int64_t r, size_t hint) -> int32_t { // block-local chunk that holds row r
+            size_t k = hint;
+            while (k > 0 && fch[base + k].out_row > r) --k;
+            while (k + 1 < cnt && fch[base + k].out_row + fch[base + k].n_frames <= r) ++k;
+            return (int32_t)k;
+        };
+        size_t k = own0;
+        const size_t own1 = own0 + (c1 - c0);
+        while (k < own1) {
+            const int u = utt_of[c0 + (k - own0)];
+            const int64_t r0 = fch[base + k].out_row;
+            int64_t rows = 0;
+            size_t k2 = k;
+            while (k2 < own1 && utt_of[c0 + (k2 - own0)] == u && rows + fch[base + k2].n_frames <= 64) {
+                rows += fch[base + k2].n_frames;
+                ++k2;
+            }
+            const int64_t u0 = h->utt_row[u], u1 = u0 + T_of[u];
+            DeltaTile t;
+            std::memset(&t, 0, sizeof(t));
+            t.out_row0 = r0;
+            t.seg_row0 = u0;
+            t.n_rows = (int32_t)rows;
+            t.r0 = (int32_t)(r0 - u0);
+            t.shift = -D;           // whole utterance: D replicated rows on both sides (as the batch Segment)
+            t.lo = 0;
+            t.hi = (int32_t)(T_of[u] - 1);
+            t.static_off = 0;
+            t.dep_lo = local_of_row(std::max(r0 - D, u0), k);
+            t.dep_hi = local_of_row(std::min(r0 + rows + D, u1) - 1, k2 - 1);
+            tiles.push_back(t);
+            k = k2;
+        }
+    }
+    coff[B] = (int32_t)fch.size();
+    toff[B] = (int32_t)tiles.size();
+    {   // one padding entry: the delta wave prefetches the descriptor after its last tile
+        DeltaTile t;
+        std::memset(&t, 0, sizeof(t));
+        tiles.push_back(t);
+    }
+    const int done_words = (int)((max_list + 31) / 32) + 1;
+    FrontParams probe;
+    fill_front(h, probe);
+    probe.dl1 = h->l1;
+    probe.dl2 = h->l2;
+    probe.done_words = done_words;
+    if (!h->fused_ok || probe.dct_mode != 1 || front512_delta_lds_bytes(probe) > 160 * 1024) return MFX_OK;
+    HIP_TRY(h, upload(h->d_fchunks, fch));
+    HIP_TRY(h, upload(h->d_blk_chunk_off, coff));
+    HIP_TRY(h, upload(h->d_blk_tile_off, toff));
+    HIP_TRY(h, upload(h->d_tiles, tiles));
+    if (!h->d_err.p) {
+        HIP_TRY(h, h->d_err.alloc(1));
+        HIP_TRY(h, hipMemset(h->d_err.p, 0, sizeof(int32_t)));
+    }
+    h->f_blocks = B;
+    h->f_done_words = done_words;
+    h->f_nchunks = (int32_t)fch.size();
+    h->fuse_plan = true;
+    return MFX_OK;
+}
+
+} // namespace
+
 extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offsets, const int64_t *lengths,
                               int64_t *out_rows, int64_t *total_rows)
 {
@@ -945,6 +1109,7 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
     h->utt_row.resize(n_utt);
     h->h_chunks.clear();
     std::vector<Segment> segs((size_t)n_utt);
+    std::vector<int64_t> T_of((size_t)n_utt);
     int64_t row = 0;
     int tiles_max = 0;
     bool aligned = (h->S % 2) == 0;
@@ -954,6 +1119,7 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
         if (T < 0) T = 0;
         if (T > 0x7fffffff) return fail(h, MFX_ERR_ARG, "utterance too long");
         h->utt_row[u] = row;
+        T_of[u] = T;
         if (out_rows) out_rows[u] = row;
         if (offsets[u] & 1) aligned = false;
         for (int64_t t0 = 0; t0 < T; t0 += kChunkFrames) {
@@ -983,6 +1149,10 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
     HIP_TRY(h, upload(h->d_chunks, h->h_chunks));
     HIP_TRY(h, upload(h->d_segs, segs));
     if (h->cfg.norm != MFX_NORM_NONE) HIP_TRY(h, h->d_stats_batch.alloc((size_t)n_utt * 3 * 2 * h->cols));
+    {
+        int rcf = plan_fused_delta(h, T_of);
+        if (rcf != MFX_OK) return rcf;
+    }
     // scratch for the compact statics (allocated here so that mfx_batch_run_device itself never allocates)
     for (int b = 0; b < (h->overlap ? 2 : 1); ++b)
         if (h->l1 > 0 && h->cols <= 16 && h->d_static16[b].n < (size_t)row * 16)
@@ -1029,7 +1199,16 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
     const int sb = h->overlap ? (int)(h->batch_seq & 1) : 0;
     const bool via_scratch = ((fused512 && p.dct_mode == 1) || fusedgen) && h->l1 > 0 && h->cols <= 16 && !norm_before &&
                              h->d_static16[sb].n >= (size_t)h->total_rows * 16;
-    const bool split_tail = h->overlap && via_scratch;
+    // Fused delta stage: the 512-point kernel's last wave per block turns the statics into whole output
+    // rows while the other 15 produce them; no separate delta launch.
+    bool fuse = h->fuse_plan && fused512 && via_scratch && ((uintptr_t)d_out & 15) == 0;
+    if (fuse) {
+        p.dl1 = h->l1;
+        p.dl2 = h->l2;
+        p.done_words = h->f_done_words;
+        fuse = p.dct_mode == 1 && front512_delta_lds_bytes(p) <= 160 * 1024;
+    }
+    const bool split_tail = h->overlap && via_scratch && !fuse;
     hipStream_t tail_stream = split_tail ? h->stream2 : h->stream;
     if (via_scratch) {
         p.feat = h->d_static16[sb].p;
@@ -1037,7 +1216,20 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
     }
     if (split_tail && h->tail_pending[sb]) // tail of batch i-2 still reads this scratch buffer
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_tail[sb], 0));
-    if (fused512) {
+    if (fuse) {
+        p.chunks = h->d_fchunks.p;
+        p.n_chunks = h->f_nchunks;
+        p.blk_chunk_off = h->d_blk_chunk_off.p;
+        p.blk_tile_off = h->d_blk_tile_off.p;
+        p.tiles = h->d_tiles.p;
+        p.out = d_out;
+        p.out_pitch = h->width;
+        p.n_blocks = h->f_blocks;
+        p.err_flag = h->d_err.p;
+        p.spec = h->d_spec.p; // unused by this kernel; a -DMFX_DSTAMPS dev build drops the delta wave's tick counts here
+        ProfScope ps(h);
+        HIP_TRY(h, launch_front512_delta(p, h->batch_aligned, h->nm16, h->stream));
+    } else if (fused512) {
         p.spec = h->d_spec.p; // unused by the fused kernel; a -DMFX_STAMPS dev build drops its cycle sums here
         ProfScope ps(h);
         HIP_TRY(h, launch_front512(p, /*to_spectrum=*/false, h->batch_aligned, h->nm16, h->stream));
@@ -1106,7 +1298,7 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
         rc = run_norm(h, d_out, h->width, 0, h->d_segs.p, h->n_utt, nullptr, 0, h->d_stats_batch.p, false);
         if (rc != MFX_OK) return rc;
     }
-    if (h->l1 > 0) {
+    if (h->l1 > 0 && !fuse) {
         DeltaParams dp;
         std::memset(&dp, 0, sizeof(dp));
         dp.src = via_scratch ? h->d_static16[sb].p : d_out;
@@ -1186,7 +1378,7 @@ extern "C" int mfx_batch_run_host(mfx_handle *h, const int16_t *pcm, int64_t pcm
     if (rc != MFX_OK) return rc;
     if (e != hipSuccess) return fail_hip(h, e, "batch copy");
     if (e2 != hipSuccess) return fail_hip(h, e2, "hipStreamSynchronize");
-    return MFX_OK;
+    return mfx_synchronize(h);
 }
 
 // ------------------------------------------------------------------------------------------------

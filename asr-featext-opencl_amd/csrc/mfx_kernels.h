@@ -34,6 +34,17 @@ struct Segment {
     int32_t pad;
 };
 
+// One tile of the delta stage fused into the 512-point kernel: <= 64 consecutive output rows of one
+// utterance, all of them inside the owning block's row range.
+struct DeltaTile {
+    int64_t out_row0;   // first output row (absolute) = first row of the statics scratch the tile owns
+    int64_t seg_row0;   // first row of the tile's utterance (statics scratch and output use the same rows)
+    int32_t n_rows;
+    int32_t r0;         // out_row0 - seg_row0
+    int32_t shift, lo, hi, static_off; // the utterance's Segment fields (padded[i] = src[clamp(i + shift, lo, hi)])
+    int32_t dep_lo, dep_hi; // block-local chunk indices whose statics the tile reads (inclusive)
+};
+
 struct FrontParams {
     const int16_t *pcm;
     int64_t pcm_total;        // int16 elements readable behind `pcm` (all channels)
@@ -72,6 +83,19 @@ struct FrontParams {
     int32_t dct_len;
     int32_t cols;             // dct_len, or num_banks when ceps_len == 0
     float scale;              // 1/W2 (0.5/W2 where the split's 1/2 is folded in)
+    // fused delta stage (512 fast path, launch_front512_delta): block b walks the chunks
+    // [blk_chunk_off[b], blk_chunk_off[b+1]) of `chunks` in order (its own rows plus <= D halo rows either
+    // side, statics to the compact scratch `feat`, pitch 16) while its last wave turns finished statics
+    // into whole [static | d | dd] rows of `out` for the tiles [blk_tile_off[b], blk_tile_off[b+1]).
+    const int32_t *blk_chunk_off;
+    const int32_t *blk_tile_off;
+    const DeltaTile *tiles;
+    float *out;
+    int32_t out_pitch;
+    int32_t dl1, dl2;
+    int32_t n_blocks;
+    int32_t done_words;       // LDS words of the per-block "chunk finished" bitmap
+    int32_t *err_flag;        // set nonzero if the delta wave gave up waiting (never expected)
 };
 
 struct MelcepParams {
@@ -123,6 +147,9 @@ struct NormParams {
 
 // All launchers are asynchronous on `stream` and return the launch status.
 hipError_t launch_front512(const FrontParams &p, bool to_spectrum, bool aligned, int nm16, hipStream_t stream);
+// fused front end + delta stage (p.blk_chunk_off etc. filled in); statics only pass through p.feat
+hipError_t launch_front512_delta(const FrontParams &p, bool aligned, int nm16, hipStream_t stream);
+size_t front512_delta_lds_bytes(const FrontParams &p);
 // fused = mel/log/DCT in the same kernel (statics to p.feat); else magnitudes to p.spec
 hipError_t launch_front_generic(const FrontParams &p, bool fused, hipStream_t stream);
 size_t front_wave_lds_bytes(const FrontParams &p, bool fused);

@@ -256,7 +256,211 @@ __device__ __forceinline__ void pcm_issue(PcmRegs<ALIGNED, NM> &r, __amdgpu_buff
 #define MFX_STAMP(i)
 #endif
 
-template <bool ALIGNED, bool TO_SPEC, int NM>
+constexpr int kDeltaRows = 64;   // output rows per tile of the delta stage (k_delta and the fused delta wave)
+
+// Arithmetic of one regression coefficient, shared by k_delta and the fused delta wave so that both give
+// the same bits: num = sum_l l*(x[t+l] - x[t-l]) accumulated in ascending l, each step one fma; the
+// quotient num / (2 sum l^2) (deltacpu.cpp:28) as reciprocal multiply + one exact-remainder correction,
+// which equals the correctly rounded quotient away from the denormal range.
+__device__ __forceinline__ float delta_quot(float num, float d, float inv)
+{
+    const float q = num * inv;
+    const float r = __builtin_fmaf(-q, d, num);
+    return __builtin_fmaf(r, inv, q);
+}
+
+// Regression numerator for 4 columns at once, split into its LDS reads and its arithmetic so that a caller
+// can put the reads of several work items in flight before the first use.  L = compile-time order.
+// Ascending l, one fma per step and column -- the same arithmetic as k_delta.
+template <int L>
+struct DeltaTaps {
+    float4 a[L], b[L];
+    __device__ __forceinline__ void load(const float4 *c)
+    {
+#pragma unroll
+        for (int l = 1; l <= L; ++l) {
+            a[l - 1] = c[4 * l];
+            b[l - 1] = c[-4 * l];
+        }
+    }
+    __device__ __forceinline__ float4 quot(float d, float inv) const
+    {
+        float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int l = 1; l <= L; ++l) {
+            const float fl = (float)l;
+            num.x = __builtin_fmaf(fl, a[l - 1].x - b[l - 1].x, num.x);
+            num.y = __builtin_fmaf(fl, a[l - 1].y - b[l - 1].y, num.y);
+            num.z = __builtin_fmaf(fl, a[l - 1].z - b[l - 1].z, num.z);
+            num.w = __builtin_fmaf(fl, a[l - 1].w - b[l - 1].w, num.w);
+        }
+        return make_float4(delta_quot(num.x, d, inv), delta_quot(num.y, d, inv), delta_quot(num.z, d, inv),
+                           delta_quot(num.w, d, inv));
+    }
+};
+
+// run-time order (any l): reads and arithmetic interleaved
+__device__ __forceinline__ float4 delta_quot4_rt(const float4 *c, int l_rt, float d, float inv)
+{
+    float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = 1; l <= l_rt; ++l) {
+        const float4 a = c[4 * l], b = c[-4 * l];
+        const float fl = (float)l;
+        num.x = __builtin_fmaf(fl, a.x - b.x, num.x);
+        num.y = __builtin_fmaf(fl, a.y - b.y, num.y);
+        num.z = __builtin_fmaf(fl, a.z - b.z, num.z);
+        num.w = __builtin_fmaf(fl, a.w - b.w, num.w);
+    }
+    return make_float4(delta_quot(num.x, d, inv), delta_quot(num.y, d, inv), delta_quot(num.z, d, inv),
+                       delta_quot(num.w, d, inv));
+}
+
+// the first `nvalid` components of v to 4 consecutive LDS words
+__device__ __forceinline__ void lds_put4(float *dst, float4 v, int nvalid)
+{
+    if (nvalid > 0) dst[0] = v.x;
+    if (nvalid > 1) dst[1] = v.y;
+    if (nvalid > 2) dst[2] = v.z;
+    if (nvalid > 3) dst[3] = v.w;
+}
+
+// LDS floats the delta wave needs: staged statics + deltas (16-float rows) and the output tile
+__host__ __device__ inline int delta_wave_lds_floats(int l1, int l2)
+{
+    return ((kDeltaRows + 2 * (l1 + l2)) + (kDeltaRows + 2 * l2)) * 16 + kDeltaRows * 48 + 8;
+}
+
+// One tile of the delta stage, rows of <= 16 columns, executed by ONE wave: rows [r0, r0 + rows) of segment
+// sg from the compact statics `src` (pitch 16, zeros beyond cols) to whole [static | d | dd] output rows.
+// A work item is a quad of 4 columns of one row.  Statics (with the clamped context rows) and deltas are
+// staged in LDS as 16-float rows; the finished rows are assembled in LDS exactly as they lie in memory
+// (same position modulo 16 bytes) and leave as aligned 16-byte stores of consecutive lanes.
+// `out` must be 16-byte aligned and out_pitch == cols * (l2 > 0 ? 3 : 2).
+template <int L1, int L2>
+__device__ __forceinline__ void delta_tile16_wave(const Segment &sg, int r0, int rows, const float *__restrict__ src,
+                                                  float *__restrict__ out, int out_pitch, int cols, int l1, int l2,
+                                                  float *smem, int lane, unsigned long long *ph = nullptr)
+{
+#ifdef MFX_DSTAMPS
+    unsigned long long ph_last, ph_t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_last)::"memory");
+#define PSTAMP(i)                                                                         \
+    do {                                                                                  \
+        __builtin_amdgcn_s_waitcnt(0);                                                    \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_t)::"memory");  \
+        ph[i] += ph_t - ph_last;                                                          \
+        ph_last = ph_t;                                                                   \
+    } while (0)
+#else
+#define PSTAMP(i)
+#endif
+    const int D = l1 + l2;
+    float4 *s_pad4 = (float4 *)smem;                      // [rows + 2D][4]
+    float4 *s_d4 = s_pad4 + (kDeltaRows + 2 * D) * 4;     // [rows + 2*l2][4]
+    float *s_out = (float *)(s_d4 + (kDeltaRows + 2 * l2) * 4); // the output tile, phase-shifted (below)
+    const int stat_row = sg.static_off - sg.shift;        // s_pad row that holds the static part of output row 0
+    // first output dword of the tile, and its position inside a 16-byte group
+    const int64_t g0 = (sg.out_row0 + r0) * (int64_t)out_pitch;
+    const int phase = (int)(g0 & 3);
+    float *so = s_out + phase;                            // so[rr * out_pitch + cc]
+    const float *sbase = src + sg.src_row0 * 16;
+    const int n_pad4 = (rows + 2 * D) * 4;   // <= (64 + 32) * 4 = 6 quads per lane
+    // all of the tile's loads go out before the first use: one memory latency per tile, not per trip
+    float4 v[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int i = lane + 64 * j;
+        const int rr = i >> 2, q = i & 3;
+        int sr = r0 + rr + sg.shift;
+        sr = max(sg.lo, min(sg.hi, sr));
+        if (i < n_pad4) v[j] = *(const float4 *)(sbase + sr * 16 + 4 * q);
+    }
+    PSTAMP(0);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int i = lane + 64 * j;
+        const int rr = i >> 2, q = i & 3;
+        if (i < n_pad4) {
+            s_pad4[i] = v[j];
+            const int orow = rr - stat_row;
+            if (orow >= 0 && orow < rows) lds_put4(so + orow * out_pitch + 4 * q, v[j], cols - 4 * q);
+        }
+    }
+    wave_sync();
+    PSTAMP(1);
+    float den = 0.f;
+    for (int l = 1; l <= l1; ++l) den += (float)(l * l);
+    const float d1 = 2 * den, inv1 = 1.0f / d1;
+    const int n_d4 = (rows + 2 * l2) * 4;
+    auto put_d = [&](int i, float4 d) {
+        const int rr = i >> 2, q = i & 3;
+        s_d4[i] = d;
+        const int orow = rr - l2;
+        if (orow >= 0 && orow < rows) lds_put4(so + orow * out_pitch + cols + 4 * q, d, cols - 4 * q);
+    };
+    if (L1 > 0) { // two work items per trip: their 4*L1 LDS reads are in flight together
+        for (int i = lane; i < n_d4; i += 128) {
+            const int i2 = i + 64 < n_d4 ? i + 64 : i;
+            DeltaTaps<(L1 > 0 ? L1 : 1)> t0, t1;
+            t0.load(s_pad4 + ((i >> 2) + l1) * 4 + (i & 3));
+            t1.load(s_pad4 + ((i2 >> 2) + l1) * 4 + (i2 & 3));
+            put_d(i, t0.quot(d1, inv1));
+            if (i2 != i) put_d(i2, t1.quot(d1, inv1));
+        }
+    } else {
+        for (int i = lane; i < n_d4; i += 64) put_d(i, delta_quot4_rt(s_pad4 + ((i >> 2) + l1) * 4 + (i & 3), l1, d1, inv1));
+    }
+    wave_sync();
+    PSTAMP(2);
+    if (l2 > 0) {
+        float den2 = 0.f;
+        for (int l = 1; l <= l2; ++l) den2 += (float)(l * l);
+        const float d2 = 2 * den2, inv2 = 1.0f / d2;
+        const int n_dd4 = rows * 4;
+        auto put_dd = [&](int i, float4 dd) {
+            const int rr = i >> 2, q = i & 3;
+            lds_put4(so + rr * out_pitch + 2 * cols + 4 * q, dd, cols - 4 * q);
+        };
+        if (L2 > 0) {
+            for (int i = lane; i < n_dd4; i += 128) {
+                const int i2 = i + 64 < n_dd4 ? i + 64 : i;
+                DeltaTaps<(L2 > 0 ? L2 : 1)> t0, t1;
+                t0.load(s_d4 + ((i >> 2) + l2) * 4 + (i & 3));
+                t1.load(s_d4 + ((i2 >> 2) + l2) * 4 + (i2 & 3));
+                put_dd(i, t0.quot(d2, inv2));
+                if (i2 != i) put_dd(i2, t1.quot(d2, inv2));
+            }
+        } else {
+            for (int i = lane; i < n_dd4; i += 64)
+                put_dd(i, delta_quot4_rt(s_d4 + ((i >> 2) + l2) * 4 + (i & 3), l2, d2, inv2));
+        }
+        wave_sync();
+    }
+    // the tile leaves: dwords [phase, phase + n) of s_out map to memory at (g0 - phase), which is 16-byte
+    // aligned; whole quads as one 16-byte store per lane, the ragged first and last quad word by word
+    const int n = rows * out_pitch, end = phase + n;
+    float *gal = out + (g0 - phase);
+    const int q_first = phase ? 1 : 0, q_last = end >> 2; // full quads: [q_first, q_last)
+    // <= 64 * 48 / 4 = 768 quads = 12 per lane, in rounds of 4: the round's LDS reads first, then its stores
+    for (int j0 = q_first + lane; j0 < q_last; j0 += 256) {
+        float4 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) // (reads are unconditional, from a clamped index: no divergent definitions)
+            w[u] = *(const float4 *)(s_out + 4 * min(j0 + 64 * u, q_last - 1));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j0 + 64 * u < q_last) *(float4 *)(gal + 4 * (j0 + 64 * u)) = w[u];
+    }
+    if (lane < 4) {
+        if (phase && lane >= phase && lane < end) gal[lane] = s_out[lane];           // head of the first quad
+        const int t = 4 * q_last + lane;                                             // tail beyond the last full quad
+        if (t < end && (t >= 4 || !phase)) gal[t] = s_out[t];
+    }
+    wave_sync();
+    PSTAMP(3);
+}
+
+template <bool ALIGNED, bool TO_SPEC, int NM, bool FUSE>
 __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -278,8 +482,15 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
     const int dct_floats = p.dct ? (p.dct_mode == 1 ? 16 : cols) * DS : 0;
     float *s_wave = s_dct + dct_floats + wave * (4 * kSlot);
     float *xb = s_wave + slot * kSlot;
-    int *s_ctr = (int *)(s_dct + dct_floats + kWaves * (4 * kSlot)); // block-local work counter
+    // FUSE: the last wave runs the delta stage; its region starts at its (unused) frame slots
+    float *s_delta = s_dct + dct_floats + (kWaves - 1) * (4 * kSlot);
+    const int delta_floats = FUSE ? delta_wave_lds_floats(p.dl1, p.dl2) : 0;
+    const int tail_floats = delta_floats > 4 * kSlot ? delta_floats : 4 * kSlot;
+    int *s_ctr = (int *)(s_dct + dct_floats + (kWaves - 1) * (4 * kSlot) + tail_floats); // block-local work counter
+    unsigned *s_done = (unsigned *)(s_ctr + 4);   // FUSE: bit k = chunk k of this block's list has its statics in memory
     if (tid == 0) *s_ctr = 0;
+    if (FUSE)
+        for (int i = tid; i < p.done_words; i += kThreads) s_done[i] = 0u;
 
     for (int i = tid; i < 256; i += kThreads) {
         // HBM tables are [lane][m]; the LDS copies are [m][lane]: one instruction reads one row,
@@ -299,6 +510,89 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
     // the slots are read (times zero weights) before every word has been written once: make them finite
     for (int i = lane; i < 4 * kSlot; i += 64) s_wave[i] = 0.f;
     __syncthreads();
+#ifdef MFX_IDLE_WAVES   // dev-only experiment: the block's last waves take no front-end work
+    if (wave >= kWaves - MFX_IDLE_WAVES) return;
+#endif
+
+    // ---- FUSE: the delta wave.  It consumes the block's tiles in order; a tile is ready once the
+    // chunks it reads (its own rows and up to D rows either side) have their bits set in s_done.  The
+    // front-end waves only ever produce, so the wait cannot deadlock; it is bounded all the same.
+    const int chunk_base = FUSE ? p.blk_chunk_off[blockIdx.x] : 0;
+    const int chunk_cnt = FUSE ? p.blk_chunk_off[blockIdx.x + 1] - chunk_base : 0;
+    if (FUSE && wave == kWaves - 1) {
+        __builtin_amdgcn_s_setprio(3); // little work, but everything it does is on the block's critical path
+        const int t_end = p.blk_tile_off[blockIdx.x + 1];
+        int t = p.blk_tile_off[blockIdx.x];
+        if (t >= t_end) return;
+        DeltaTile T = p.tiles[t];
+#ifdef MFX_DSTAMPS
+        unsigned long long ds_acc[4] = {0, 0, 0, 0}, ds_last, ds_t, ds_ph[4] = {0, 0, 0, 0};
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ds_last)::"memory");
+        const unsigned long long ds_begin = ds_last;
+#define DSTAMP(i)                                                                         \
+    do {                                                                                  \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ds_t)::"memory");  \
+        ds_acc[i] += ds_t - ds_last;                                                      \
+        ds_last = ds_t;                                                                   \
+    } while (0)
+#else
+#define DSTAMP(i)
+#endif
+        for (; t < t_end; ++t) {
+            // the next descriptor is fetched while this tile is worked on (one past the end is a valid
+            // address: the host pads the tile array by one entry)
+            const DeltaTile nxt = p.tiles[t + 1];
+            const int lo = __builtin_amdgcn_readfirstlane(T.dep_lo), hi = __builtin_amdgcn_readfirstlane(T.dep_hi);
+            bool ok = false;
+            for (int spins = 0; spins < (1 << 22); ++spins) {
+                ok = true;
+                for (int w = lo >> 5; w <= (hi >> 5); ++w) {
+                    const int b0 = max(lo - 32 * w, 0), b1 = min(hi - 32 * w, 31);
+                    const unsigned mask = (b1 == 31 ? 0xffffffffu : ((1u << (b1 + 1)) - 1u)) & ~((1u << b0) - 1u);
+                    const unsigned v = __hip_atomic_load(&s_done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if ((v & mask) != mask) ok = false;
+                }
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!ok) { // never expected: report instead of hanging
+                if (lane == 0 && p.err_flag) atomicExch(p.err_flag, 1);
+                return;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            DSTAMP(0);
+            Segment sg;
+            sg.src_row0 = sg.out_row0 = T.seg_row0;
+            sg.n_out = 0;
+            sg.shift = T.shift;
+            sg.lo = T.lo;
+            sg.hi = T.hi;
+            sg.static_off = T.static_off;
+            sg.pad = 0;
+#ifdef MFX_DSTAMPS
+            unsigned long long *php = ds_ph;
+#else
+            unsigned long long *php = nullptr;
+#endif
+            if (p.dl1 == 3 && p.dl2 == 3) // the reference driver's orders (ASR_OCL.cpp:560): reads unrolled
+                delta_tile16_wave<3, 3>(sg, T.r0, T.n_rows, p.feat, p.out, p.out_pitch, cols, 3, 3, s_delta, lane, php);
+            else
+                delta_tile16_wave<0, 0>(sg, T.r0, T.n_rows, p.feat, p.out, p.out_pitch, cols, p.dl1, p.dl2, s_delta, lane, php);
+            DSTAMP(1);
+            T = nxt;
+        }
+#ifdef MFX_DSTAMPS
+        if (lane == 0 && p.spec) { // 100 MHz ticks: waiting, working, whole life, tiles
+            unsigned long long *o = (unsigned long long *)p.spec + (size_t)blockIdx.x * 8;
+            o[0] = ds_acc[0];
+            o[1] = ds_acc[1];
+            o[2] = ds_last - ds_begin;
+            o[3] = (unsigned long long)(t_end - p.blk_tile_off[blockIdx.x]);
+            for (int i = 0; i < 4; ++i) o[4 + i] = ds_ph[i];
+        }
+#endif
+        return;
+    }
 
     const float scale = p.scale;
 
@@ -354,6 +648,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
         return k;
     };
     auto chunk_of = [&](int k) -> int {
+        if (FUSE) return k < chunk_cnt ? chunk_base + k : p.n_chunks; // the block's own contiguous list, in order
         const long long c = (long long)blockIdx.x + (long long)k * gridDim.x;
         return c < p.n_chunks ? (int)c : p.n_chunks;
     };
@@ -581,6 +876,12 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
             MFX_STAMP(6);
         }
         if (n_live <= 0) pcm_issue<ALIGNED, NM>(cur, cnxt.rsrc, lane_off(cnxt, slot)); // empty chunk: nothing was prefetched
+        if (FUSE) { // the chunk's statics are on their way to memory: publish it to the delta wave
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const int kk = c_cur - chunk_base;
+            if (lane == 0)
+                __hip_atomic_fetch_or(&s_done[kk >> 5], 1u << (kk & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         // rotate the pipeline: next -> current, the index drawn a chunk ago -> next, draw another
         c_cur = c_nxt;
         ccur = cnxt;
@@ -793,8 +1094,6 @@ __global__ void __launch_bounds__(256) k_melcep(MelcepParams p)
 // MfccCpu::do_delta (mfcccpu.cpp:234-263) expressed as a clamped row accessor (Segment).
 // grid = (tiles, segments); one tile = kDeltaRows output rows.
 // ------------------------------------------------------------------------------------------------
-constexpr int kDeltaRows = 64;
-
 // FAST16: cols <= 16 -> a row is 16 consecutive work items (no integer division by a run-time
 // column count, 13..16 consecutive floats per row piece); otherwise the generic index split.
 template <bool FAST16>
@@ -832,11 +1131,13 @@ __global__ void __launch_bounds__(256) k_delta(DeltaParams p)
         __syncthreads();
         float den = 0.f;
         for (int l = 1; l <= l1; ++l) den += (float)(l * l);
+        const float d1 = 2 * den, inv1 = 1.0f / d1;
         const int n_d = (rows + 2 * l2) * cw;
         for (int i = tid; i < n_d; i += 256) {
             float num = 0.f;
-            for (int l = 1; l <= l1; ++l) num += (float)l * (s_pad[i + (l1 + l) * cw] - s_pad[i + (l1 - l) * cw]);
-            s_d[i] = num / (2 * den);
+            for (int l = 1; l <= l1; ++l)
+                num = __builtin_fmaf((float)l, s_pad[i + (l1 + l) * cw] - s_pad[i + (l1 - l) * cw], num);
+            s_d[i] = delta_quot(num, d1, inv1);
         }
         __syncthreads();
     }
@@ -844,11 +1145,13 @@ __global__ void __launch_bounds__(256) k_delta(DeltaParams p)
     if (l2 > 0) {
         float den2 = 0.f;
         for (int l = 1; l <= l2; ++l) den2 += (float)(l * l);
+        const float d2 = 2 * den2, inv2 = 1.0f / d2;
         const int n_dd = rows * cw;
         for (int i = tid; i < n_dd; i += 256) {
             float num = 0.f;
-            for (int l = 1; l <= l2; ++l) num += (float)l * (s_d[i + (l2 + l) * cw] - s_d[i + (l2 - l) * cw]);
-            s_dd[i] = num / (2 * den2);
+            for (int l = 1; l <= l2; ++l)
+                num = __builtin_fmaf((float)l, s_d[i + (l2 + l) * cw] - s_d[i + (l2 - l) * cw], num);
+            s_dd[i] = delta_quot(num, d2, inv2);
         }
         __syncthreads();
     }
@@ -983,7 +1286,29 @@ size_t front512_lds_bytes(const FrontParams &p)
     return f * sizeof(float);
 }
 
+size_t front512_delta_lds_bytes(const FrontParams &p)
+{
+    const size_t delta_floats = (size_t)delta_wave_lds_floats(p.dl1, p.dl2);
+    size_t f = front512_lds_bytes(p) / sizeof(float);
+    if (delta_floats > (size_t)4 * kSlot) f += delta_floats - 4 * kSlot; // the delta wave's region grows past its frame slots
+    f += (size_t)p.done_words;
+    return f * sizeof(float);
+}
+
 namespace {
+
+template <bool A, int NM>
+hipError_t launch512_delta(const FrontParams &p, hipStream_t stream)
+{
+    const size_t lds = front512_delta_lds_bytes(p);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_front512<A, false, NM, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_front512<A, false, NM, true>), dim3(p.n_blocks), dim3(kThreads), lds, stream, p);
+    return hipGetLastError();
+}
 
 template <bool A, bool S, int NM>
 hipError_t launch512(const FrontParams &p_in, hipStream_t stream)
@@ -997,7 +1322,7 @@ hipError_t launch512(const FrontParams &p_in, hipStream_t stream)
     }
     const size_t lds = front512_lds_bytes(p);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_front512<A, S, NM>,
+        hipError_t e = hipFuncSetAttribute((const void *)k_front512<A, S, NM, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
@@ -1005,7 +1330,7 @@ hipError_t launch512(const FrontParams &p_in, hipStream_t stream)
     const int cap = num_cus() * (32 / kWaves) / 2; // 16 waves per CU
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_front512<A, S, NM>), dim3(blocks), dim3(kThreads), lds, stream, p);
+    hipLaunchKernelGGL((k_front512<A, S, NM, false>), dim3(blocks), dim3(kThreads), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -1036,6 +1361,14 @@ hipError_t launch_front512(const FrontParams &p, bool to_spectrum, bool aligned,
     }
     if (aligned) return nm13 ? launch512<true, false, 13>(p, stream) : launch512<true, false, 16>(p, stream);
     return nm13 ? launch512<false, false, 13>(p, stream) : launch512<false, false, 16>(p, stream);
+}
+
+hipError_t launch_front512_delta(const FrontParams &p, bool aligned, int nm16, hipStream_t stream)
+{
+    if (p.n_chunks <= 0 || p.n_blocks <= 0) return hipSuccess;
+    const bool nm13 = nm16 <= 13;
+    if (aligned) return nm13 ? launch512_delta<true, 13>(p, stream) : launch512_delta<true, 16>(p, stream);
+    return nm13 ? launch512_delta<false, 13>(p, stream) : launch512_delta<false, 16>(p, stream);
 }
 
 size_t front_wave_lds_bytes(const FrontParams &p, bool fused)

@@ -689,3 +689,64 @@ def test_batch_overlap_mode_is_bit_identical(pkg, orc):
     assert torch.equal(o, ref[0])
     want = orc.run_utterance(cfg, pcms[2][5].cpu().numpy(), w, bug_compat=False)
     assert_close(outs[2][rows[5]:rows[5] + want.shape[0]].cpu().numpy(), want, "overlap mode vs oracle", groups=3)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused delta stage of the 512-point kernel (one wave per block consumes the other 15 waves' statics)
+# ---------------------------------------------------------------------------------------------
+
+def _fuse_pair(pkg, orc, monkeypatch, **kw):
+    """Two extractors with identical parameters: fused delta stage on (opt-in, MFX_FUSE_DELTA=1) and off."""
+    monkeypatch.setenv("MFX_FUSE_DELTA", "1")
+    m_f, cfg, w = make_pair(pkg, orc, 200000, **kw)
+    monkeypatch.setenv("MFX_FUSE_DELTA", "0")
+    m_u, _, _ = make_pair(pkg, orc, 200000, **kw)
+    monkeypatch.delenv("MFX_FUSE_DELTA")
+    return m_f, m_u, cfg, w
+
+
+@pytest.mark.parametrize("dyn,l1,l2,norm", [(2, 3, 3, 0), (2, 2, 5, 0), (1, 4, 0, 0), (2, 1, 1, 2), (2, 8, 8, 0)])
+def test_fused_delta_bit_identical_to_separate_kernel(pkg, orc, monkeypatch, dyn, l1, l2, norm):
+    """The fused path must give the SAME BITS as front end + k_delta (same arithmetic, same order), over
+    ragged utterances: block pieces that start/end inside an utterance (halo chunks), utterances shorter than
+    the delta context, empty ones, and lengths that leave 1..3 live frames in the last iteration."""
+    lens = [160000, 5000, 400, 720, 1040, 1200, 0, 48000, 2000, 12346, 30000, 1360, 100000, 880]
+    offs, pos = [], 0
+    for n in lens:
+        offs.append(pos)
+        pos += n + (n & 1)
+    pcm = np.zeros(pos + 8, np.int16)
+    for u, (o_, n) in enumerate(zip(offs, lens)):
+        pcm[o_:o_ + n] = synth_utterance(n, 100 + u)
+    m_f, m_u, cfg, w = _fuse_pair(pkg, orc, monkeypatch, dyn=dyn, l1=l1, l2=l2, norm=norm)
+    rows_f, total_f = m_f.batch_plan(offs, lens)
+    rows_u, total_u = m_u.batch_plan(offs, lens)
+    assert total_f == total_u and list(rows_f) == list(rows_u)
+    got_f = m_f.batch_run_host(pcm)
+    got_u = m_u.batch_run_host(pcm)
+    # (CVN of a 1-frame utterance is 0/0 in the reference too: NaN on both sides)
+    assert got_f.shape == got_u.shape and np.array_equal(got_f, got_u, equal_nan=True)
+    # and both agree with the oracle on a long and a short utterance
+    # (not with normalisation: the batch normalises per utterance, the streaming oracle per block)
+    for u in (0, 9, 12) if norm == 0 else ():
+        T = max((lens[u] - 240) // 160, 0)
+        want = orc.run_utterance(cfg, pcm[offs[u]:offs[u] + lens[u]], w, bug_compat=False)
+        assert_close(got_f[rows_f[u]:rows_f[u] + T], want, "fused delta utt %d" % u, groups=groups_of(dyn))
+
+
+def test_fused_delta_many_blocks_full_shape(pkg, orc, monkeypatch):
+    """C2-shaped batch big enough to use every CU (one block per CU, ~60 tiles per block): fused and
+    separate paths bit-identical, repeated launches stable."""
+    n_utt, n = 300, 160000
+    rng = np.random.default_rng(5)
+    pcm = (rng.standard_normal(n_utt * n) * 3000).astype(np.int16)
+    offs = [u * n for u in range(n_utt)]
+    m_f, m_u, cfg, w = _fuse_pair(pkg, orc, monkeypatch)
+    m_f.batch_plan(offs, [n] * n_utt)
+    m_u.batch_plan(offs, [n] * n_utt)
+    a = m_f.batch_run_host(pcm)
+    b = m_u.batch_run_host(pcm)
+    assert a.shape == (n_utt * 998, 39) and np.array_equal(a, b)
+    assert np.array_equal(m_f.batch_run_host(pcm), a)
+    want = orc.run_utterance(cfg, pcm[7 * n:8 * n], w, bug_compat=False)
+    assert_close(a[7 * 998:8 * 998], want, "utt 7", groups=3)
