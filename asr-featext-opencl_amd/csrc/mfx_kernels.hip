@@ -594,8 +594,6 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
         return;
     }
 
-    const float scale = p.scale;
-
 #ifdef MFX_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_rt0;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt0)::"memory");
@@ -744,10 +742,10 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
                 const float dr = a[pp].x - zr, di = a[pp].y + zi;
                 const float xr = sr + (cs.x * dr - cs.y * di);
                 const float xi = si + (cs.x * di + cs.y * dr);
-                mag[pp] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi) * scale;
+                mag[pp] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi); // the window taps carry 0.5 / W2
             }
             // Nyquist bin: X[256] = Re Z[0] - Im Z[0]
-            const float nyq = fabsf(a[0].x - a[0].y) * (2.0f * scale);
+            const float nyq = 2.0f * fabsf(a[0].x - a[0].y);
 #endif
 
             MFX_STAMP(5);
