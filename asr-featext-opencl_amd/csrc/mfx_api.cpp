@@ -106,6 +106,7 @@ struct mfx_handle {
     int64_t total_rows = 0;
     std::vector<int64_t> utt_off, utt_len, utt_row;
     std::vector<Chunk> h_chunks;
+    std::vector<int32_t> chunk_utt;      // utterance of every entry of h_chunks
     DevBuf<Chunk> d_chunks;
     DevBuf<Segment> d_segs;
     DevBuf<float> d_stats_batch, d_spec_slab;
@@ -983,15 +984,7 @@ int plan_fused_delta(mfx_handle *h, const std::vector<int64_t> &T_of)
         return MFX_OK;
     const int D = h->D;
     const int B = (int)std::min<size_t>((size_t)h->num_cus, (n + 14) / 15);
-    // utterance of every chunk
-    std::vector<int32_t> utt_of(n);
-    {
-        size_t c = 0;
-        for (int u = 0; u < h->n_utt; ++u) {
-            const size_t cnt = (size_t)((T_of[u] + kChunkFrames - 1) / kChunkFrames);
-            for (size_t k = 0; k < cnt; ++k) utt_of[c++] = u;
-        }
-    }
+    const std::vector<int32_t> &utt_of = h->chunk_utt; // utterance of every chunk
     std::vector<Chunk> fch;
     fch.reserve(n + 2 * (size_t)B);
     std::vector<DeltaTile> tiles;
@@ -1112,6 +1105,7 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
     h->utt_len.assign(lengths, lengths + n_utt);
     h->utt_row.resize(n_utt);
     h->h_chunks.clear();
+    h->chunk_utt.clear();
     std::vector<Segment> segs((size_t)n_utt);
     std::vector<int64_t> T_of((size_t)n_utt);
     int64_t row = 0;
@@ -1133,6 +1127,7 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
             c.n_frames = (int32_t)std::min<int64_t>(kChunkFrames, T - t0);
             c.pad = 0;
             h->h_chunks.push_back(c);
+            h->chunk_utt.push_back(u);
         }
         Segment &s = segs[u];
         std::memset(&s, 0, sizeof(s));
@@ -1145,6 +1140,33 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
         s.static_off = 0;
         tiles_max = std::max<int>(tiles_max, (int)((T + 63) / 64));
         row += T;
+    }
+    // The 512-point kernel deals chunks to the 16 waves of each block as they become free; with 16-frame
+    // chunks a wave can sit idle for most of a chunk time (~34 us on C2) at the end of the launch.  The last two
+    // chunks of every wave of the grid are therefore cut into 4-frame pieces (one kernel iteration each).
+    const char *ts = std::getenv("MFX_TAIL_SPLIT");
+    if (h->fast512 && !(ts && ts[0] == '0')) {
+        const size_t n = h->h_chunks.size();
+        const size_t tail = std::min<size_t>(n, (size_t)(ts && ts[0] > '0' ? ts[0] - '0' : 2) * 16 * h->num_cus);
+        if (n >= 4 * tail) { // only when the launch is long enough for the tail to matter
+            std::vector<Chunk> cut;
+            std::vector<int32_t> cut_utt;
+            for (size_t c = n - tail; c < n; ++c) {
+                const Chunk &src = h->h_chunks[c];
+                for (int f = 0; f < src.n_frames; f += 4) {
+                    Chunk q = src;
+                    q.pcm_off = src.pcm_off + (int64_t)f * h->S;
+                    q.out_row = src.out_row + f;
+                    q.n_frames = std::min(4, src.n_frames - f);
+                    cut.push_back(q);
+                    cut_utt.push_back(h->chunk_utt[c]);
+                }
+            }
+            h->h_chunks.resize(n - tail);
+            h->chunk_utt.resize(n - tail);
+            h->h_chunks.insert(h->h_chunks.end(), cut.begin(), cut.end());
+            h->chunk_utt.insert(h->chunk_utt.end(), cut_utt.begin(), cut_utt.end());
+        }
     }
     h->total_rows = row;
     h->tiles_max = tiles_max;
