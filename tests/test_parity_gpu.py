@@ -459,6 +459,77 @@ def test_c2_full_size_properties(pkg, orc):
 # the C++ mirror (class MfccHip : MfccBase) and the afet-style driver built on it
 # ---------------------------------------------------------------------------------------------
 
+def test_c4_per_gpu_share_full_size_properties(pkg, orc):
+    """BASELINE configs[3] per GPU: 12 500 utterances x 10 s = 2.0e9 samples (4 GB of PCM, byte offsets past
+    2^32) -> 12 475 000 frames.  The batch is 25 copies of one 500-utterance block, so every copy of the
+    output must equal the first bit for bit, and the first must equal the block run on its own."""
+    import torch
+    blk_utt, copies, n = 500, 25, 160000
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 12 * 2 ** 30:
+        pytest.skip("needs 12 GiB of free HBM")
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    blk = (3000.0 * torch.randn((blk_utt, n), generator=g, device=dev)).round().clamp(-32768, 32767).to(torch.int16)
+    pcm = blk.repeat(copies, 1)
+    n_utt = blk_utt * copies
+    m, cfg, w = make_pair(pkg, orc, n + 1000)
+    rows, total = m.batch_plan(np.arange(n_utt, dtype=np.int64) * n, np.full(n_utt, n, dtype=np.int64))
+    assert total == 998 * n_utt == 12475000
+    out = torch.empty((total, 39), dtype=torch.float32, device=dev)
+    out.fill_(float("nan"))
+    m.batch_run_device(pcm.data_ptr(), pcm.numel(), out.data_ptr())
+    m.synchronize()
+    per = 998 * blk_utt
+    first = out[:per]
+    assert bool(torch.isfinite(first).all())
+    for c in range(1, copies):
+        assert torch.equal(out[c * per:(c + 1) * per], first), "copy %d differs" % c
+    m2, _, _ = make_pair(pkg, orc, n + 1000)
+    m2.batch_plan(np.arange(blk_utt, dtype=np.int64) * n, np.full(blk_utt, n, dtype=np.int64))
+    alone = torch.empty((per, 39), dtype=torch.float32, device=dev)
+    m2.batch_run_device(blk.data_ptr(), blk.numel(), alone.data_ptr())
+    m2.synchronize()
+    assert torch.equal(alone, first)
+    want = orc.run_utterance(cfg, blk[7].cpu().numpy(), w, bug_compat=False)
+    assert_close(out[(24 * blk_utt + 7) * 998:(24 * blk_utt + 8) * 998].cpu().numpy(), want, "C4 share, last copy, utt 7", groups=3)
+
+
+def test_c3_full_size_stream_properties(pkg, orc):
+    """BASELINE configs[2] at full size: one 57 600 000-sample stream (1 hour), 1024-point FFT, 80 mel, 13 MFCC,
+    no deltas -> 359 998 frames.  Without deltas a frame depends on its own 400 samples only, so the stream cut
+    in two overlapping utterances must reproduce the same rows bit for bit."""
+    import torch
+    n = 57600000
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    pcm = (3000.0 * torch.randn(n, generator=g, device=dev)).round().clamp(-32768, 32767).to(torch.int16)
+    m, cfg, w_o = make_pair(pkg, orc, 20000, nb=80, dyn=0, fft_size=1024)
+    rows, total = m.batch_plan([0], [n])
+    assert total == (n - 240) // 160 == 359998
+    out = torch.empty((total, 13), dtype=torch.float32, device=dev)
+    out.fill_(float("nan"))
+    m.batch_run_device(pcm.data_ptr(), pcm.numel(), out.data_ptr())
+    m.synchronize()
+    assert bool(torch.isfinite(out).all())
+    cut = 180000                                   # frames in the first piece
+    m2, _, _ = make_pair(pkg, orc, 20000, nb=80, dyn=0, fft_size=1024)
+    r2, t2 = m2.batch_plan([0, cut * 160], [cut * 160 + 240, n - cut * 160])
+    assert t2 == total and list(r2) == [0, cut]
+    out2 = torch.empty_like(out)
+    m2.batch_run_device(pcm.data_ptr(), pcm.numel(), out2.data_ptr())
+    m2.synchronize()
+    assert torch.equal(out, out2)
+    # sampled parity: a 2-second excerpt from the middle against the oracle (same frames, same samples)
+    f0 = 200000
+    seg = pcm[f0 * 160:f0 * 160 + 32000 + 1024].cpu().numpy()
+    want = orc.run_utterance(cfg, seg, w_o, bug_compat=False)
+    k = min(want.shape[0], 190)
+    assert_close(out[f0:f0 + k].cpu().numpy(), want[:k], "C3 excerpt")
+
+
 def test_cpp_driver_text_output(orc, a0001, tmp_path):
     """asr-featext-opencl_amd/host/afet_hip: the reference's per-file loop (ASR_OCL.cpp:163-321) in
     C++ over MfccHip; its text rows ("| time | v | v | ...", %f) must match the oracle."""
