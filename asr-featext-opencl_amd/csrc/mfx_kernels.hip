@@ -330,17 +330,51 @@ __host__ __device__ inline int delta_wave_lds_floats(int l1, int l2)
     return ((kDeltaRows + 2 * (l1 + l2)) + (kDeltaRows + 2 * l2)) * 16 + kDeltaRows * 48 + 8;
 }
 
-// One tile of the delta stage, rows of <= 16 columns, executed by ONE wave: rows [r0, r0 + rows) of segment
+// One tile of the delta stage, rows of <= 16 columns, executed by NT threads (`lane` = thread index): rows
+// [r0, r0 + rows) of segment
 // sg from the compact statics `src` (pitch 16, zeros beyond cols) to whole [static | d | dd] output rows.
 // A work item is a quad of 4 columns of one row.  Statics (with the clamped context rows) and deltas are
 // staged in LDS as 16-float rows; the finished rows are assembled in LDS exactly as they lie in memory
 // (same position modulo 16 bytes) and leave as aligned 16-byte stores of consecutive lanes.
 // `out` must be 16-byte aligned and out_pitch == cols * (l2 > 0 ? 3 : 2).
-template <int L1, int L2>
-__device__ __forceinline__ void delta_tile16_wave(const Segment &sg, int r0, int rows, const float *__restrict__ src,
-                                                  float *__restrict__ out, int out_pitch, int cols, int l1, int l2,
-                                                  float *smem, int lane, unsigned long long *ph = nullptr)
+// The statics of one tile on their way from memory: (64 + 32) staged rows x 4 quads over NT threads.
+template <int NT>
+struct DeltaFill {
+    static constexpr int kFill = (96 * 4 + NT - 1) / NT;
+    float4 v[kFill];
+    // issue the loads of rows [r0 - D, r0 + rows + D) of the segment (clamped, mfcccpu.cpp:243-256)
+    __device__ __forceinline__ void issue(const Segment &sg, int r0, int rows, int D, const float *__restrict__ src, int lane)
+    {
+        const float *sbase = src + sg.src_row0 * 16;
+        const int n_pad4 = (rows + 2 * D) * 4;
+#pragma unroll
+        for (int j = 0; j < kFill; ++j) {
+            const int i = lane + NT * j;
+            const int rr = i >> 2, q = i & 3;
+            int sr = r0 + rr + sg.shift;
+            sr = max(sg.lo, min(sg.hi, sr));
+            if (i < n_pad4) v[j] = *(const float4 *)(sbase + sr * 16 + 4 * q);
+        }
+    }
+};
+
+template <int L1, int L2, int NT>
+__device__ __forceinline__ void delta_tile16(const Segment &sg, int r0, int rows, const float *__restrict__ src,
+                                             float *__restrict__ out, int out_pitch, int cols, int l1, int l2,
+                                             float *smem, int lane, DeltaFill<NT> &fill, int next_r0, int next_rows,
+                                             unsigned long long *ph = nullptr)
 {
+    // `fill` holds this tile's loads (DeltaFill::issue); once they are staged in LDS the loads of the
+    // tile at next_r0 (next_rows > 0) are issued into it and fly during the rest of this tile.
+    // NT = 64: one wave (wave-level ordering is enough); NT = 256: a whole block
+    auto sync = [] {
+        if (NT == 64)
+            wave_sync();
+        else
+            __syncthreads();
+    };
+    constexpr int kFill = DeltaFill<NT>::kFill;
+    float4(&v)[kFill] = fill.v;
 #ifdef MFX_DSTAMPS
     unsigned long long ph_last, ph_t;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_last)::"memory");
@@ -363,22 +397,11 @@ __device__ __forceinline__ void delta_tile16_wave(const Segment &sg, int r0, int
     const int64_t g0 = (sg.out_row0 + r0) * (int64_t)out_pitch;
     const int phase = (int)(g0 & 3);
     float *so = s_out + phase;                            // so[rr * out_pitch + cc]
-    const float *sbase = src + sg.src_row0 * 16;
-    const int n_pad4 = (rows + 2 * D) * 4;   // <= (64 + 32) * 4 = 6 quads per lane
-    // all of the tile's loads go out before the first use: one memory latency per tile, not per trip
-    float4 v[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int i = lane + 64 * j;
-        const int rr = i >> 2, q = i & 3;
-        int sr = r0 + rr + sg.shift;
-        sr = max(sg.lo, min(sg.hi, sr));
-        if (i < n_pad4) v[j] = *(const float4 *)(sbase + sr * 16 + 4 * q);
-    }
+    const int n_pad4 = (rows + 2 * D) * 4;   // <= (64 + 32) * 4 quads
     PSTAMP(0);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int i = lane + 64 * j;
+    for (int j = 0; j < kFill; ++j) {
+        const int i = lane + NT * j;
         const int rr = i >> 2, q = i & 3;
         if (i < n_pad4) {
             s_pad4[i] = v[j];
@@ -386,7 +409,8 @@ __device__ __forceinline__ void delta_tile16_wave(const Segment &sg, int r0, int
             if (orow >= 0 && orow < rows) lds_put4(so + orow * out_pitch + 4 * q, v[j], cols - 4 * q);
         }
     }
-    wave_sync();
+    if (next_rows > 0) fill.issue(sg, next_r0, next_rows, D, src, lane);
+    sync();
     PSTAMP(1);
     float den = 0.f;
     for (int l = 1; l <= l1; ++l) den += (float)(l * l);
@@ -398,19 +422,25 @@ __device__ __forceinline__ void delta_tile16_wave(const Segment &sg, int r0, int
         const int orow = rr - l2;
         if (orow >= 0 && orow < rows) lds_put4(so + orow * out_pitch + cols + 4 * q, d, cols - 4 * q);
     };
-    if (L1 > 0) { // two work items per trip: their 4*L1 LDS reads are in flight together
-        for (int i = lane; i < n_d4; i += 128) {
-            const int i2 = i + 64 < n_d4 ? i + 64 : i;
+    if (L1 > 0 && NT == 64) { // one wave: two work items per trip, their 4*L1 LDS reads in flight together
+        for (int i = lane; i < n_d4; i += 2 * NT) {
+            const int i2 = i + NT < n_d4 ? i + NT : i;
             DeltaTaps<(L1 > 0 ? L1 : 1)> t0, t1;
             t0.load(s_pad4 + ((i >> 2) + l1) * 4 + (i & 3));
             t1.load(s_pad4 + ((i2 >> 2) + l1) * 4 + (i2 & 3));
             put_d(i, t0.quot(d1, inv1));
             if (i2 != i) put_d(i2, t1.quot(d1, inv1));
         }
+    } else if (L1 > 0) {      // a block: about one work item per thread
+        for (int i = lane; i < n_d4; i += NT) {
+            DeltaTaps<(L1 > 0 ? L1 : 1)> t0;
+            t0.load(s_pad4 + ((i >> 2) + l1) * 4 + (i & 3));
+            put_d(i, t0.quot(d1, inv1));
+        }
     } else {
-        for (int i = lane; i < n_d4; i += 64) put_d(i, delta_quot4_rt(s_pad4 + ((i >> 2) + l1) * 4 + (i & 3), l1, d1, inv1));
+        for (int i = lane; i < n_d4; i += NT) put_d(i, delta_quot4_rt(s_pad4 + ((i >> 2) + l1) * 4 + (i & 3), l1, d1, inv1));
     }
-    wave_sync();
+    sync();
     PSTAMP(2);
     if (l2 > 0) {
         float den2 = 0.f;
@@ -421,20 +451,26 @@ __device__ __forceinline__ void delta_tile16_wave(const Segment &sg, int r0, int
             const int rr = i >> 2, q = i & 3;
             lds_put4(so + rr * out_pitch + 2 * cols + 4 * q, dd, cols - 4 * q);
         };
-        if (L2 > 0) {
-            for (int i = lane; i < n_dd4; i += 128) {
-                const int i2 = i + 64 < n_dd4 ? i + 64 : i;
+        if (L2 > 0 && NT == 64) {
+            for (int i = lane; i < n_dd4; i += 2 * NT) {
+                const int i2 = i + NT < n_dd4 ? i + NT : i;
                 DeltaTaps<(L2 > 0 ? L2 : 1)> t0, t1;
                 t0.load(s_d4 + ((i >> 2) + l2) * 4 + (i & 3));
                 t1.load(s_d4 + ((i2 >> 2) + l2) * 4 + (i2 & 3));
                 put_dd(i, t0.quot(d2, inv2));
                 if (i2 != i) put_dd(i2, t1.quot(d2, inv2));
             }
+        } else if (L2 > 0) {
+            for (int i = lane; i < n_dd4; i += NT) {
+                DeltaTaps<(L2 > 0 ? L2 : 1)> t0;
+                t0.load(s_d4 + ((i >> 2) + l2) * 4 + (i & 3));
+                put_dd(i, t0.quot(d2, inv2));
+            }
         } else {
-            for (int i = lane; i < n_dd4; i += 64)
+            for (int i = lane; i < n_dd4; i += NT)
                 put_dd(i, delta_quot4_rt(s_d4 + ((i >> 2) + l2) * 4 + (i & 3), l2, d2, inv2));
         }
-        wave_sync();
+        sync();
     }
     // the tile leaves: dwords [phase, phase + n) of s_out map to memory at (g0 - phase), which is 16-byte
     // aligned; whole quads as one 16-byte store per lane, the ragged first and last quad word by word
@@ -442,21 +478,21 @@ __device__ __forceinline__ void delta_tile16_wave(const Segment &sg, int r0, int
     float *gal = out + (g0 - phase);
     const int q_first = phase ? 1 : 0, q_last = end >> 2; // full quads: [q_first, q_last)
     // <= 64 * 48 / 4 = 768 quads = 12 per lane, in rounds of 4: the round's LDS reads first, then its stores
-    for (int j0 = q_first + lane; j0 < q_last; j0 += 256) {
+    for (int j0 = q_first + lane; j0 < q_last; j0 += 4 * NT) {
         float4 w[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) // (reads are unconditional, from a clamped index: no divergent definitions)
-            w[u] = *(const float4 *)(s_out + 4 * min(j0 + 64 * u, q_last - 1));
+            w[u] = *(const float4 *)(s_out + 4 * min(j0 + NT * u, q_last - 1));
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (j0 + 64 * u < q_last) *(float4 *)(gal + 4 * (j0 + 64 * u)) = w[u];
+            if (j0 + NT * u < q_last) *(float4 *)(gal + 4 * (j0 + NT * u)) = w[u];
     }
     if (lane < 4) {
         if (phase && lane >= phase && lane < end) gal[lane] = s_out[lane];           // head of the first quad
         const int t = 4 * q_last + lane;                                             // tail beyond the last full quad
         if (t < end && (t >= 4 || !phase)) gal[t] = s_out[t];
     }
-    wave_sync();
+    sync();
     PSTAMP(3);
 }
 
@@ -574,10 +610,13 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
 #else
             unsigned long long *php = nullptr;
 #endif
+            DeltaFill<64> fill;
+            fill.issue(sg, T.r0, T.n_rows, p.dl1 + p.dl2, p.feat, lane);
             if (p.dl1 == 3 && p.dl2 == 3) // the reference driver's orders (ASR_OCL.cpp:560): reads unrolled
-                delta_tile16_wave<3, 3>(sg, T.r0, T.n_rows, p.feat, p.out, p.out_pitch, cols, 3, 3, s_delta, lane, php);
+                delta_tile16<3, 3, 64>(sg, T.r0, T.n_rows, p.feat, p.out, p.out_pitch, cols, 3, 3, s_delta, lane, fill, 0, 0, php);
             else
-                delta_tile16_wave<0, 0>(sg, T.r0, T.n_rows, p.feat, p.out, p.out_pitch, cols, p.dl1, p.dl2, s_delta, lane, php);
+                delta_tile16<0, 0, 64>(sg, T.r0, T.n_rows, p.feat, p.out, p.out_pitch, cols, p.dl1, p.dl2, s_delta, lane, fill,
+                                       0, 0, php);
             DSTAMP(1);
             T = nxt;
         }
@@ -1190,6 +1229,32 @@ __global__ void __launch_bounds__(256) k_delta(DeltaParams p)
     }
 }
 
+// Delta stage from the compact statics (pitch 16) to whole output rows: the tile function of the fused
+// delta wave run by a block.  grid = (tiles, segments) as k_delta; requires cols <= 16, l1 > 0,
+// out_pitch == cols * (l2 > 0 ? 3 : 2), src_pitch == 16 and a 16-byte aligned `out`.
+constexpr int kDelta16TilesPerBlock = 2;
+
+template <int L1, int L2>
+__global__ void __launch_bounds__(256, 7) k_delta16(DeltaParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Segment sg = p.inline_seg ? p.seg0 : p.segs[blockIdx.y];
+    int r0 = blockIdx.x * (kDelta16TilesPerBlock * kDeltaRows);
+    if (r0 >= sg.n_out) return;
+    // a block walks 2 consecutive tiles (measured on C2: 1 -> 62 us, 2 -> 59 us, 4 -> 62 us, 8 -> 71 us per launch); the
+    // statics of the second are in flight while the first is computed
+    DeltaFill<256> fill;
+    fill.issue(sg, r0, min(kDeltaRows, sg.n_out - r0), p.l1 + p.l2, p.src, threadIdx.x);
+#pragma unroll 1
+    for (int t = 0; t < kDelta16TilesPerBlock && r0 < sg.n_out; ++t, r0 += kDeltaRows) {
+        const int rows = min(kDeltaRows, sg.n_out - r0);
+        const int nr0 = r0 + kDeltaRows;
+        const int nrows = (t + 1 < kDelta16TilesPerBlock && nr0 < sg.n_out) ? min(kDeltaRows, sg.n_out - nr0) : 0;
+        delta_tile16<L1, L2, 256>(sg, r0, rows, p.src, p.out, p.out_pitch, p.cols, p.l1, p.l2, smem, threadIdx.x, fill, nr0,
+                                  nrows);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // normalisation (normalizercpu.cpp:22-89): per segment, per column statistics in double.
 // stats layout [seg][2][cols]: mean, multiplier.
@@ -1436,6 +1501,23 @@ hipError_t launch_delta(const DeltaParams &p, hipStream_t stream)
 {
     if (p.n_segs <= 0 || p.tiles_per_seg_max <= 0) return hipSuccess;
     const int D = p.l1 + p.l2;
+    const int groups = p.l2 > 0 ? 3 : 2;
+    if (p.cols <= 16 && p.l1 > 0 && D <= 16 && p.src_pitch == 16 && p.out_pitch == p.cols * groups &&
+        ((uintptr_t)p.out & 15) == 0 && ((uintptr_t)p.src & 15) == 0) {
+        const size_t lds16 = (size_t)delta_wave_lds_floats(p.l1, p.l2) * sizeof(float);
+        const bool u33 = p.l1 == 3 && p.l2 == 3;
+        const int tiles_x = (p.tiles_per_seg_max + kDelta16TilesPerBlock - 1) / kDelta16TilesPerBlock;
+        for (int s0 = 0; s0 < p.n_segs; s0 += 65535) {
+            DeltaParams q = p;
+            q.segs = p.segs + s0;
+            q.n_segs = (p.n_segs - s0) < 65535 ? (p.n_segs - s0) : 65535;
+            if (u33)
+                hipLaunchKernelGGL((k_delta16<3, 3>), dim3(tiles_x, q.n_segs), dim3(256), lds16, stream, q);
+            else
+                hipLaunchKernelGGL((k_delta16<0, 0>), dim3(tiles_x, q.n_segs), dim3(256), lds16, stream, q);
+        }
+        return hipGetLastError();
+    }
     const bool fast16 = p.cols <= 16;
     const int cw = fast16 ? 16 : p.cols;
     const size_t lds = (size_t)((kDeltaRows + 2 * D) + (kDeltaRows + 2 * p.l2) + kDeltaRows) * cw * sizeof(float);

@@ -1,0 +1,8 @@
+#!/bin/bash
+# dev aid: rocprofv3 kernel stats of the default bench, first lines (run on the GPU box)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=${1:-kstats}
+cd /tmp && export TMPDIR=/tmp
+rm -rf "$R/gpurun_out/$TAG"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/$TAG" -- python3 "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$R/gpurun_out/$TAG.json" 2> "$R/gpurun_out/$TAG.err"
+head -4 "$R"/gpurun_out/$TAG/*/*kernel_stats.csv | cut -c1-170
