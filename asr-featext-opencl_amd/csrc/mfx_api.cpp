@@ -203,6 +203,7 @@ void fill_front(const mfx_handle *h, FrontParams &p)
 {
     std::memset(&p, 0, sizeof(p));
     p.channels = h->channels;
+    p.pair_ok = (h->channels == 1 && (h->S % 2) == 0 && (h->W % 2) == 0 && h->batch_aligned) ? 1 : 0;
     p.window_size = h->W;
     p.shift = h->S;
     p.fft_size = h->W2;
@@ -646,6 +647,7 @@ int stream_front(mfx_handle *h, int wcnd)
     p.n_chunks = (wcnd + kChunkFrames - 1) / kChunkFrames;
     p.row_limit = wcnd;
     p.channels = 1;
+    p.pair_ok = ((h->S % 2) == 0 && (h->W % 2) == 0) ? 1 : 0; // carry-buffer frames start at multiples of S
     p.spec = h->d_spec.p;
     p.spec_pitch = h->spec_pitch;
     if (h->fast512)

@@ -50,7 +50,8 @@ struct FrontParams {
     int64_t pcm_total;        // int16 elements readable behind `pcm` (all channels)
     const Chunk *chunks;
     int32_t n_chunks;
-    int32_t channels;         // 1 or 2 (generic kernel only)
+    int32_t channels;         // 1 or 2 (generic kernels only)
+    int32_t pair_ok;          // mono, even shift, even window length, even chunk offsets: 2 samples per 32-bit load
     int64_t row_limit;        // frames whose destination row is >= row_limit are skipped
     int32_t window_size;      // W
     int32_t shift;            // S

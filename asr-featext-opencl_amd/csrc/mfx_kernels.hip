@@ -89,39 +89,69 @@ __device__ __forceinline__ void fft16(float2 (&x)[16])
 // (mfcccpu.cpp:192-220, `while` semantics for coincident edges); out[c] = sum_m mel[m]*dct[m][c] in
 // ascending m (mfcccpu.cpp:222-232).  Tables are read from LDS copies (s_*).
 // ------------------------------------------------------------------------------------------------
+// LDS floats of the scratch behind `melbuf`: the log mel energies + the partial sums of the chunked DCT
+__host__ __device__ inline int mel_scratch_floats(int nb, int cols) { return ((nb + 3) & ~3) + 8 * ((cols + 3) & ~3); }
+
+// walk one filter's bins in ascending order, 8 bins per trip (the 16 LDS reads are issued together)
+__device__ __forceinline__ float mel_filter_sum(const float *w, const float *mag, int b0, int b1)
+{
+    float acc = 0.f;
+    int k = b0;
+    for (; k + 8 <= b1; k += 8) {
+        float wv[8], mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            wv[u] = w[k + u];
+            mv[u] = mag[k + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += wv[u] * mv[u];
+    }
+    for (; k < b1; ++k) acc += w[k] * mag[k];
+    return acc;
+}
+
 template <int G>
 __device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int g, const float *s_w0,
                                             const float *s_w1, const int *s_beg, const float *s_dct, int nb,
                                             int dct_len, int cols, float *out_row)
 {
-    for (int m = g; m < nb; m += G) {
-        const int b0 = s_beg[m], b1 = s_beg[m + 2];
-        const float *w = (m & 1) ? s_w1 : s_w0;
-        float acc = 0.f;
-        int k = b0;
-        // 8 bins per trip: the 16 LDS reads are issued together, the sum stays in ascending bin order
-        for (; k + 8 <= b1; k += 8) {
-            float wv[8], mv[8];
+    static_assert(G == 64, "one wave per frame");
+    // Mel filters are narrow at the bottom and wide at the top of the band: lane i takes filter i AND
+    // filter nb-1-i, so every lane walks about the same number of bins (each filter still sums its own
+    // bins in ascending order, as the reference).
+    const int half = (nb + 1) >> 1;
+    for (int i = g; i < half; i += G) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                wv[u] = w[k + u];
-                mv[u] = mag[k + u];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += wv[u] * mv[u];
+        for (int t = 0; t < 2; ++t) {
+            const int m = t == 0 ? i : nb - 1 - i;
+            if (t == 1 && m == i) break; // the middle filter of an odd bank
+            const float acc = mel_filter_sum((m & 1) ? s_w1 : s_w0, mag, s_beg[m], s_beg[m + 2]);
+            melbuf[m] = logf(fmaxf(acc, 1e-30f));
         }
-        for (; k < b1; ++k) acc += w[k] * mag[k];
-        melbuf[m] = logf(fmaxf(acc, 1e-30f));
     }
-    if (G > 64)
-        __syncthreads();
-    else
-        wave_sync();
+    wave_sync();
     if (s_dct) {
-        for (int c = g; c < cols; c += G) {
+        // DCT: out[c] = sum_m mel[m] * dct[m][c].  The m range is cut into n_ch chunks so that the (column,
+        // chunk) items fill the 64 lanes; a chunk is summed in ascending m, the chunks are added in
+        // ascending order by the column's lane (mfcccpu.cpp:222-232 sums m = 0..nb-1 in one chain: same
+        // terms, association differs by the chunk boundaries only).
+        int n_ch = 1, best = nb; // cost ~ rounds * terms per item
+        for (int c2 = 2; c2 <= 8; c2 <<= 1) {
+            const int cost = ((cols * c2 + G - 1) / G) * ((nb + c2 - 1) / c2);
+            if (cost < best) {
+                best = cost;
+                n_ch = c2;
+            }
+        }
+        const int ch_len = (nb + n_ch - 1) / n_ch, cols4 = (cols + 3) & ~3;
+        float *part = melbuf + ((nb + 3) & ~3); // [n_ch][cols4]
+        for (int it = g; it < cols * n_ch; it += G) {
+            const int ch = it / cols, c = it - ch * cols;
+            const int m0 = ch * ch_len, m1 = min(nb, m0 + ch_len);
             float acc = 0.f;
-            int m = 0;
-            for (; m + 8 <= nb; m += 8) { // reads batched 8 deep, sum in ascending m
+            int m = m0;
+            for (; m + 8 <= m1; m += 8) { // reads batched 8 deep
                 float ev[8], dv[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -131,8 +161,19 @@ __device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc += ev[u] * dv[u];
             }
-            for (; m < nb; ++m) acc += melbuf[m] * s_dct[m * dct_len + c];
-            out_row[c] = acc;
+            for (; m < m1; ++m) acc += melbuf[m] * s_dct[m * dct_len + c];
+            if (n_ch == 1)
+                out_row[c] = acc;
+            else
+                part[ch * cols4 + c] = acc;
+        }
+        if (n_ch > 1) {
+            wave_sync();
+            for (int c = g; c < cols; c += G) {
+                float acc = part[c];
+                for (int ch = 1; ch < n_ch; ++ch) acc += part[ch * cols4 + c];
+                out_row[c] = acc;
+            }
         }
     } else {
         for (int c = g; c < cols; c += G) out_row[c] = melbuf[c];
@@ -939,15 +980,16 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Generic front end: any power-of-two FFT length 64..4096, mono or stereo, any alignment.
+// Generic front end for the short transforms (64..512 points; 512 only when the register kernel above
+// cannot take the configuration: stereo, more than 16 columns ...), mono or stereo, any alignment.
+// Transforms of 1024 points and more run in k_front_reg below.
 // One WAVE per frame (4 waves per block, each walking its own chunks): half-size complex Stockham
 // FFT in the wave's own LDS buffers -- radix-4 stages, one radix-2 stage when log2 is odd, only
 // wave-level synchronisation -- then the real split and the magnitudes.
 //   FUSED: mel -> log -> DCT straight from LDS (no spectrum round trip through HBM), statics out;
 //   else : magnitudes to the HBM spectrum buffer (streaming set_input).
 // ------------------------------------------------------------------------------------------------
-// G = threads that share one frame: 64 (a wave; wave-level synchronisation only) or 256 (the whole
-// block; for long transforms, where one frame per wave would leave too few waves per CU for its LDS).
+// G = threads that share one frame: 64 (a wave; wave-level synchronisation only).
 template <bool FUSED, int G>
 __global__ void __launch_bounds__(256) k_front_wave(FrontParams p)
 {
@@ -971,7 +1013,7 @@ __global__ void __launch_bounds__(256) k_front_wave(FrontParams p)
     float *s_dct = (float *)(s_beg + beg_pad);
     const int dct_floats = (FUSED && p.dct) ? nb * dl : 0;
     const int dct_pad = (dct_floats + 3) & ~3;
-    const int nb_pad = FUSED ? ((nb + 3) & ~3) : 0;
+    const int nb_pad = FUSED ? mel_scratch_floats(nb, p.cols) : 0;
     float *s_wave = s_dct + dct_pad + wave * (4 * M + nb_pad);
     float2 *bufA = (float2 *)s_wave;
     float2 *bufB = bufA + M;
@@ -1084,6 +1126,220 @@ __global__ void __launch_bounds__(256) k_front_wave(FrontParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Long transforms (1024 / 2048 / 4096 points): one WAVE per frame, the half-size complex FFT as three
+// Stockham passes whose butterflies (radix 16 / 8 / 4) run in registers.  Every pass reads all of its
+// inputs into registers before it writes, so the frame needs ONE LDS buffer of M complex points and the
+// three passes cost three LDS round trips (the radix-4 loop of k_front_wave: five or six, two buffers).
+//   M =  512:  8 x  8 x 8          M = 1024: 16 x 16 x 4          M = 2048: 16 x 16 x 8
+// Pass 1 takes its inputs straight from the PCM loads (lane l needs z[l + (M/R) r]: exactly the strided
+// samples it loaded); the last pass has no twiddles.  The real split pairs bins k and M - k: one
+// partner fetch gives both magnitudes (|S + T| and |S - T|).  Tables (pass twiddles W_M^k, split twiddles,
+// window pairs with the output scale folded in) are shared by the block's waves in LDS.
+//   FUSED (M = 512): mel -> log -> DCT from the magnitudes in LDS; else magnitudes to the HBM spectrum.
+//   PAIR: mono, even shift / offsets / window length -> two samples per 32-bit load.
+// ------------------------------------------------------------------------------------------------
+// 8-point forward DFT in registers, natural order in and out
+__device__ __forceinline__ void fft8(float2 (&x)[8])
+{
+    constexpr float R = 0.70710678118654752440f;
+    float2 e[4], o[4];
+    dft4(x[0], x[2], x[4], x[6], e[0], e[1], e[2], e[3]);
+    dft4(x[1], x[3], x[5], x[7], o[0], o[1], o[2], o[3]);
+    float2 t;
+    t = o[1]; o[1] = make_float2(R * (t.x + t.y), R * (t.y - t.x));   // W8^1
+    t = o[2]; o[2] = make_float2(t.y, -t.x);                          // W8^2 = -i
+    t = o[3]; o[3] = make_float2(R * (t.y - t.x), -R * (t.x + t.y));  // W8^3
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        x[k] = make_float2(e[k].x + o[k].x, e[k].y + o[k].y);
+        x[k + 4] = make_float2(e[k].x - o[k].x, e[k].y - o[k].y);
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void fft_r(float2 (&v)[R])
+{
+    if (R == 16) {
+        fft16(reinterpret_cast<float2(&)[16]>(v));
+    } else if (R == 8) {
+        fft8(reinterpret_cast<float2(&)[8]>(v));
+    } else {
+        float2 o0, o1, o2, o3;
+        dft4(v[0], v[1], v[2], v[3], o0, o1, o2, o3);
+        v[0] = o0;
+        v[1] = o1;
+        v[2] = o2;
+        v[3] = o3;
+    }
+}
+
+// One Stockham pass of radix R over the M points in `buf` (in place: all reads, then all writes), sub-transform
+// length LEN before the pass, stride ST = M / LEN.  NB = butterflies per lane.  `v` in/out: with FROM_REGS the
+// inputs are already in v (pass 1), otherwise they are read from buf.
+template <int M, int R, int LEN, bool FROM_REGS>
+__device__ __forceinline__ void stockham_pass(float2 *buf, const float2 *s_tw, int lane, float2 (&v)[M / 64])
+{
+    constexpr int ST = M / LEN, N1 = LEN / R, NB = M / R / 64;
+    static_assert(NB >= 1, "a pass needs at least one butterfly per lane");
+    if (!FROM_REGS) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int idx = lane + 64 * b, pp = idx / ST, q = idx % ST;
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[b * R + r] = buf[q + ST * (pp + r * N1)];
+        }
+        wave_sync();
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int idx = lane + 64 * b, pp = idx / ST, q = idx % ST;
+        float2(&w)[R] = reinterpret_cast<float2(&)[R]>(v[b * R]);
+        fft_r<R>(w);
+        buf[q + ST * (R * pp)] = w[0];
+#pragma unroll
+        for (int k = 1; k < R; ++k)
+            buf[q + ST * (R * pp + k)] = (LEN == R) ? w[k] : cmul(w[k], s_tw[(pp * k * ST) & (M - 1)]); // W_LEN^(pp k)
+    }
+    wave_sync();
+}
+
+template <int LOG2M, bool FUSED, bool PAIR>
+__global__ void __launch_bounds__(LOG2M >= 11 ? 256 : 1024) k_front_reg(FrontParams p)
+{
+    constexpr int M = 1 << LOG2M, W2 = 2 * M, NV = M / 64;
+    constexpr int R1 = (LOG2M == 9) ? 8 : 16, R2 = R1, R3 = M / (R1 * R2);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
+    const int nb = p.num_banks, dl = p.dct_len;
+    // shared tables, then one buffer of M complex points (+ mel scratch) per wave
+    float2 *s_tw = (float2 *)smem;                 // [M]   W_M^k
+    float2 *s_cs = s_tw + M;                       // [M/2 + 1]  -i W_{2M}^k (one per bin pair), padded to even
+    float2 *s_win = s_cs + (M / 2 + 2);            // [M]   (w[2n], w[2n+1]) * 0.5 / W2
+    float *s_w0 = (float *)(s_win + M);
+    constexpr int bins_pad = (M + 1 + 3) & ~3;
+    float *s_w1 = s_w0 + (FUSED ? bins_pad : 0);
+    int *s_beg = (int *)(s_w1 + (FUSED ? bins_pad : 0));
+    const int beg_pad = FUSED ? ((nb + 2 + 3) & ~3) : 0;
+    float *s_dct = (float *)(s_beg + beg_pad);
+    const int dct_floats = (FUSED && p.dct) ? nb * dl : 0;
+    const int dct_pad = (dct_floats + 3) & ~3;
+    const int nb_pad = FUSED ? mel_scratch_floats(nb, p.cols) : 0;
+    float *s_wave = s_dct + dct_pad + wave * (2 * M + nb_pad);
+    float2 *buf = (float2 *)s_wave;
+    float *s_mel = s_wave + 2 * M;
+
+    const float scale = p.scale; // 0.5 / W2, a power of two: folded into the window taps (exact)
+    for (int i = tid; i < M; i += blockDim.x) {
+        s_tw[i] = ((const float2 *)p.twid_half)[i];
+        const float2 wv = ((const float2 *)p.window)[i];
+        s_win[i] = make_float2(wv.x * scale, wv.y * scale);
+    }
+    for (int i = tid; i <= M / 2; i += blockDim.x) s_cs[i] = ((const float2 *)p.twid_split)[i];
+    if (FUSED) {
+        for (int i = tid; i < M + 1; i += blockDim.x) {
+            s_w0[i] = p.mel_w[i];
+            s_w1[i] = p.mel_w[W2 + i];
+        }
+        for (int i = tid; i < nb + 2; i += blockDim.x) s_beg[i] = p.mel_beg[i];
+        for (int i = tid; i < dct_floats; i += blockDim.x) s_dct[i] = p.dct[i];
+    }
+    __syncthreads();
+
+    const int ch_n = p.channels, W = p.window_size;
+    for (int c = blockIdx.x * n_waves + wave; c < p.n_chunks; c += gridDim.x * n_waves) {
+        const Chunk ch = p.chunks[c];
+        for (int f = 0; f < ch.n_frames && (ch.out_row + f) < p.row_limit; ++f) {
+            const int64_t s0 = ch.pcm_off + (int64_t)f * p.shift;
+            // ---- framing + window, straight into the registers of pass 1: z[n], n = lane + 64 j
+            float2 v[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int n = lane + 64 * j;
+                float x0 = 0.f, x1 = 0.f;
+                if (2 * n < W) {
+                    if (PAIR) {
+                        const uint32_t d = ((const uint32_t *)(p.pcm + s0))[n];
+                        x0 = (float)(int)(short)(d & 0xffffu);
+                        x1 = (float)((int)d >> 16);
+                    } else if (ch_n == 2) {
+                        const int64_t s = s0 + 2 * n;
+                        x0 = (float)(((int)p.pcm[2 * s] + (int)p.pcm[2 * s + 1]) >> 1); // stereo -> mono (L + R) >> 1
+                        if (2 * n + 1 < W) x1 = (float)(((int)p.pcm[2 * s + 2] + (int)p.pcm[2 * s + 3]) >> 1);
+                    } else {
+                        const int64_t s = s0 + 2 * n;
+                        x0 = (float)(int)p.pcm[s];
+                        if (2 * n + 1 < W) x1 = (float)(int)p.pcm[s + 1];
+                    }
+                }
+                const float2 w = s_win[n];
+                v[j] = make_float2(w.x * x0, w.y * x1);
+            }
+            // Pass 1 wants, per butterfly b, its R1 inputs z[pp + (M/R1) r] contiguous in v: with NB1 = M/R1/64
+            // butterflies per lane, z[lane + 64 j] is input r = j / NB1 of butterfly b = j % NB1.
+            {
+                constexpr int NB1 = M / R1 / 64;
+                if (NB1 > 1) {
+                    float2 t[NV];
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) t[(j % NB1) * R1 + j / NB1] = v[j];
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) v[j] = t[j];
+                }
+            }
+            stockham_pass<M, R1, M, true>(buf, s_tw, lane, v);
+#if !defined(MFX_REG_ABL) || MFX_REG_ABL < 2
+            stockham_pass<M, R2, M / R1, false>(buf, s_tw, lane, v);
+            stockham_pass<M, R3, R3, false>(buf, s_tw, lane, v);
+#endif
+
+            // ---- real split over the bin pairs (k, M - k), k = lane + 64 j <= M/2, and the magnitudes
+            constexpr int NP = M / 128; // pairs per lane (+ the self-paired k = M/2 on lane 0)
+            float mag_lo[NP + 1], mag_hi[NP + 1];
+#pragma unroll
+            for (int j = 0; j <= NP; ++j) {
+                const int k = (j < NP) ? lane + 64 * j : M / 2;
+                const float2 zk = buf[k], zm = buf[(M - k) & (M - 1)];
+                const float sr = zk.x + zm.x, si = zk.y - zm.y;
+                const float dr = zk.x - zm.x, di = zk.y + zm.y;
+                const float2 w = s_cs[k];
+                const float tr = w.x * dr - w.y * di, ti = w.x * di + w.y * dr;
+                const float ar = sr + tr, ai = si + ti, br = sr - tr, bi = si - ti;
+                mag_lo[j] = __builtin_amdgcn_sqrtf(ar * ar + ai * ai); // |X[k]| / W2
+                mag_hi[j] = __builtin_amdgcn_sqrtf(br * br + bi * bi); // |X[M - k]| / W2
+            }
+            wave_sync();
+            if (FUSED) {
+                float *mag = (float *)buf; // in place: every complex point has been read
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const int k = lane + 64 * j;
+                    mag[k] = mag_lo[j];
+                    mag[M - k] = mag_hi[j];
+                }
+                if (lane == 0) mag[M / 2] = mag_lo[NP];
+                wave_sync();
+#if defined(MFX_REG_ABL) && MFX_REG_ABL >= 1
+                if (lane < p.cols) p.feat[(ch.out_row + f) * (int64_t)p.feat_pitch + lane] = mag[lane];
+#else
+                mel_log_dct<64>(mag, s_mel, lane, s_w0, s_w1, s_beg, p.dct ? s_dct : nullptr, nb, dl, p.cols,
+                                p.feat + (ch.out_row + f) * (int64_t)p.feat_pitch);
+#endif
+                wave_sync();
+            } else {
+                float *dst = p.spec + (ch.out_row + f) * (int64_t)p.spec_pitch;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const int k = lane + 64 * j;
+                    dst[k] = mag_lo[j];
+                    dst[M - k] = mag_hi[j];
+                }
+                if (lane == 0) dst[M / 2] = mag_lo[NP];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // melcep: stored magnitudes -> mel -> log -> DCT.  One wave per frame, 4 waves per block.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_melcep(MelcepParams p)
@@ -1100,7 +1356,7 @@ __global__ void __launch_bounds__(256) k_melcep(MelcepParams p)
     float *s_dct = (float *)(s_beg + beg_pad);
     const int dct_floats = p.dct ? nb * dl : 0;
     const int dct_pad = (dct_floats + 3) & ~3;
-    const int nb_pad = (nb + 3) & ~3;
+    const int nb_pad = mel_scratch_floats(nb, p.cols);
     float *s_mag = s_dct + dct_pad + wave * (bins_pad + nb_pad);
     float *s_mel = s_mag + bins_pad;
 
@@ -1434,45 +1690,92 @@ hipError_t launch_front512_delta(const FrontParams &p, bool aligned, int nm16, h
     return nm13 ? launch512_delta<false, 13>(p, stream) : launch512_delta<false, 16>(p, stream);
 }
 
+namespace {
+
+bool use_front_reg(const FrontParams &p) { return p.fft_size == 1024 || p.fft_size == 2048 || p.fft_size == 4096; }
+
+// LDS floats of k_front_reg: shared tables + per wave one complex buffer (+ mel scratch when fused)
+size_t front_reg_lds_floats(const FrontParams &p, bool fused, int n_waves)
+{
+    const size_t M = (size_t)p.fft_size >> 1;
+    size_t f = 2 * M + 2 * (M / 2 + 2) + 2 * M; // pass twiddles, split twiddles, window pairs
+    if (fused) {
+        f += 2 * ((M + 1 + 3) & ~(size_t)3) + ((p.num_banks + 2 + 3) & ~3);
+        f += ((p.dct ? (size_t)p.num_banks * p.dct_len : 0) + 3) & ~(size_t)3;
+    }
+    f += (size_t)n_waves * (2 * M + (fused ? mel_scratch_floats(p.num_banks, p.cols) : 0));
+    return f;
+}
+
+// waves per block of k_front_reg: as many of 16 / 8 / 4 as the CU's 160 KB of LDS allows (0: does not fit)
+int front_reg_waves(const FrontParams &p, bool fused)
+{
+    // (4096 points: 4 waves -- the kernel is built for 256 threads there, its 32 points per lane need the registers)
+    for (int nw = p.fft_size >= 4096 ? 4 : 16; nw >= 4; nw >>= 1)
+        if (front_reg_lds_floats(p, fused, nw) * sizeof(float) <= 160 * 1024) return nw;
+    return 0;
+}
+
+template <int LOG2M, bool FUSED>
+hipError_t launch_reg(const FrontParams &p, int nw, hipStream_t stream)
+{
+    const size_t lds = front_reg_lds_floats(p, FUSED, nw) * sizeof(float);
+    const void *fn = p.pair_ok ? (const void *)k_front_reg<LOG2M, FUSED, true> : (const void *)k_front_reg<LOG2M, FUSED, false>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    int blocks = (p.n_chunks + nw - 1) / nw;
+    const int cap = num_cus() * (lds * 2 <= 160 * 1024 && nw <= 16 ? 2 : 1);
+    if (blocks > cap) blocks = cap;
+    if (p.pair_ok)
+        hipLaunchKernelGGL((k_front_reg<LOG2M, FUSED, true>), dim3(blocks), dim3(64 * nw), lds, stream, p);
+    else
+        hipLaunchKernelGGL((k_front_reg<LOG2M, FUSED, false>), dim3(blocks), dim3(64 * nw), lds, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace
+
 size_t front_wave_lds_bytes(const FrontParams &p, bool fused)
 {
+    if (use_front_reg(p)) {
+        const int nw = front_reg_waves(p, fused);
+        return nw ? front_reg_lds_floats(p, fused, nw) * sizeof(float) : (size_t)1 << 30;
+    }
     const int M = p.fft_size >> 1, nbins = M + 1, bins_pad = (nbins + 3) & ~3;
     size_t f = 0;
     if (fused) {
         f += 2 * (size_t)bins_pad + ((p.num_banks + 2 + 3) & ~3);
         f += ((p.dct ? (size_t)p.num_banks * p.dct_len : 0) + 3) & ~(size_t)3;
     }
-    const int groups = p.fft_size >= 2048 ? 1 : 4; // frames in flight per block (see launch_front_generic)
-    f += groups * ((size_t)4 * M + (fused ? ((p.num_banks + 3) & ~3) : 0));
+    f += 4 * ((size_t)4 * M + (fused ? mel_scratch_floats(p.num_banks, p.cols) : 0));
     return f * sizeof(float);
 }
 
 hipError_t launch_front_generic(const FrontParams &p, bool fused, hipStream_t stream)
 {
     if (p.n_chunks <= 0) return hipSuccess;
+    if (use_front_reg(p)) { // long transforms: register-pass kernel
+        const int nw = front_reg_waves(p, fused);
+        if (nw == 0) return hipErrorInvalidValue;
+        if (p.fft_size == 1024) return fused ? launch_reg<9, true>(p, nw, stream) : launch_reg<9, false>(p, nw, stream);
+        if (fused) return hipErrorInvalidValue; // callers fuse up to 1024 points only
+        return p.fft_size == 2048 ? launch_reg<10, false>(p, nw, stream) : launch_reg<11, false>(p, nw, stream);
+    }
     const size_t lds = front_wave_lds_bytes(p, fused);
-    const bool wide = p.fft_size >= 2048; // one frame per block instead of one per wave
-    const void *fn = wide ? (fused ? (const void *)k_front_wave<true, 256> : (const void *)k_front_wave<false, 256>)
-                          : (fused ? (const void *)k_front_wave<true, 64> : (const void *)k_front_wave<false, 64>);
+    const void *fn = fused ? (const void *)k_front_wave<true, 64> : (const void *)k_front_wave<false, 64>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const int per_block = wide ? 1 : 4;
-    int blocks = (p.n_chunks + per_block - 1) / per_block;
+    int blocks = (p.n_chunks + 3) / 4;
     const int cap = num_cus() * 8;
     if (blocks > cap) blocks = cap;
-    if (wide) {
-        if (fused)
-            hipLaunchKernelGGL((k_front_wave<true, 256>), dim3(blocks), dim3(256), lds, stream, p);
-        else
-            hipLaunchKernelGGL((k_front_wave<false, 256>), dim3(blocks), dim3(256), lds, stream, p);
-    } else {
-        if (fused)
-            hipLaunchKernelGGL((k_front_wave<true, 64>), dim3(blocks), dim3(256), lds, stream, p);
-        else
-            hipLaunchKernelGGL((k_front_wave<false, 64>), dim3(blocks), dim3(256), lds, stream, p);
-    }
+    if (fused)
+        hipLaunchKernelGGL((k_front_wave<true, 64>), dim3(blocks), dim3(256), lds, stream, p);
+    else
+        hipLaunchKernelGGL((k_front_wave<false, 64>), dim3(blocks), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -1482,7 +1785,7 @@ hipError_t launch_melcep(const MelcepParams &p, hipStream_t stream)
     const int nbins = (p.fft_size >> 1) + 1, bins_pad = (nbins + 3) & ~3;
     const int nb = p.num_banks;
     size_t f = 2 * bins_pad + ((nb + 2 + 3) & ~3) + (((p.dct ? nb * p.dct_len : 0) + 3) & ~3) +
-               4 * (bins_pad + ((nb + 3) & ~3));
+               4 * (bins_pad + mel_scratch_floats(nb, p.cols));
     const size_t lds = f * sizeof(float);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)k_melcep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -718,9 +718,10 @@ def test_random_configuration(pkg, orc, case):
     g = groups_of(c["dyn"])
     # CMN/CVN: the output is rescaled by 1/sigma of each column, which amplifies the float32 noise floor of
     # the un-normalised features (a few 1e-6 of their scale) by scale/sigma -- large for the nearly
-    # constant delta-delta columns -- so the comparison is looser there; un-normalised configurations
-    # keep the 1e-4 / 1e-5 bar
-    tol = dict(tol_max=1e-3, tol_l2=2e-4) if c["norm"] else {}
+    # constant delta-delta columns -- so the comparison is looser there: the un-normalised bar (1e-5 of the
+    # signal scale in L2) times scale/sigma of order 30 gives a few 1e-4 of the unit variance.
+    # Un-normalised configurations keep the 1e-4 / 1e-5 bar.
+    tol = dict(tol_max=2e-3, tol_l2=5e-4) if c["norm"] else {}
     assert_close(m.process_stream(pcm), orc.run_utterance(cfg, pcm, w), "stream", groups=g, **tol)
     if not c["norm"]:   # batch normalisation is per utterance, the reference's is per block
         m.batch_plan([0], [pcm.size])
