@@ -1214,9 +1214,9 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
     // Which front end: the 512-point register kernel, else the fused wave-per-frame kernel when its
     // LDS fits, else spectrum through an HBM slab + melcep.
     const bool fused512 = h->fast512 && h->fused_ok;
-    // (for 2048 points and more the single-kernel form loses: one frame occupies a whole block, and the
-    // serial walk over the widest mel filters then idles it -- spectrum + melcep keeps 4 frames per block)
-    const bool fusedgen = !fused512 && h->W2 <= 1024 && front_wave_lds_bytes(p, true) <= 160 * 1024;
+    // (up to 2048 points the fused form saves the spectrum's round trip through HBM -- 8 KB per frame at 2048
+    // points; at 4096 points the tables + per-wave buffers no longer leave enough waves per CU)
+    const bool fusedgen = !fused512 && h->W2 <= 2048 && front_wave_lds_bytes(p, true) <= 160 * 1024;
     // With deltas on, the front end writes its statics as compact 64-byte rows into a scratch buffer
     // and the delta kernel emits whole [static | d | dd] rows: every HBM write is then a full line
     // (13-float row pieces at a 156-byte pitch cost 1.5x their size in 32-byte sectors).

@@ -1176,7 +1176,16 @@ __device__ __forceinline__ void fft_r(float2 (&v)[R])
 // One Stockham pass of radix R over the M points in `buf` (in place: all reads, then all writes), sub-transform
 // length LEN before the pass, stride ST = M / LEN.  NB = butterflies per lane.  `v` in/out: with FROM_REGS the
 // inputs are already in v (pass 1), otherwise they are read from buf.
-template <int M, int R, int LEN, bool FROM_REGS>
+// Padded LDS layout of the complex buffer: one empty slot after every 2^LP points.  The first pass writes
+// R consecutive points per lane (lane stride R * 8 bytes: without the pad all lanes of an access fall on the
+// same bank pair, a 32-way conflict); with it the stride is odd in 8-byte slots.
+template <int LP>
+__device__ __forceinline__ int pad_idx(int i)
+{
+    return i + (i >> LP);
+}
+
+template <int M, int R, int LEN, bool FROM_REGS, int LP>
 __device__ __forceinline__ void stockham_pass(float2 *buf, const float2 *s_tw, int lane, float2 (&v)[M / 64])
 {
     constexpr int ST = M / LEN, N1 = LEN / R, NB = M / R / 64;
@@ -1186,7 +1195,7 @@ __device__ __forceinline__ void stockham_pass(float2 *buf, const float2 *s_tw, i
         for (int b = 0; b < NB; ++b) {
             const int idx = lane + 64 * b, pp = idx / ST, q = idx % ST;
 #pragma unroll
-            for (int r = 0; r < R; ++r) v[b * R + r] = buf[q + ST * (pp + r * N1)];
+            for (int r = 0; r < R; ++r) v[b * R + r] = buf[pad_idx<LP>(q + ST * (pp + r * N1))];
         }
         wave_sync();
     }
@@ -1195,19 +1204,21 @@ __device__ __forceinline__ void stockham_pass(float2 *buf, const float2 *s_tw, i
         const int idx = lane + 64 * b, pp = idx / ST, q = idx % ST;
         float2(&w)[R] = reinterpret_cast<float2(&)[R]>(v[b * R]);
         fft_r<R>(w);
-        buf[q + ST * (R * pp)] = w[0];
+        buf[pad_idx<LP>(q + ST * (R * pp))] = w[0];
 #pragma unroll
         for (int k = 1; k < R; ++k)
-            buf[q + ST * (R * pp + k)] = (LEN == R) ? w[k] : cmul(w[k], s_tw[(pp * k * ST) & (M - 1)]); // W_LEN^(pp k)
+            buf[pad_idx<LP>(q + ST * (R * pp + k))] =
+                (LEN == R) ? w[k] : cmul(w[k], s_tw[(pp * k * ST) & (M - 1)]); // W_LEN^(pp k)
     }
     wave_sync();
 }
 
 template <int LOG2M, bool FUSED, bool PAIR>
-__global__ void __launch_bounds__(LOG2M >= 11 ? 256 : 1024) k_front_reg(FrontParams p)
+__global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 512 : 1024) k_front_reg(FrontParams p)
 {
     constexpr int M = 1 << LOG2M, W2 = 2 * M, NV = M / 64;
     constexpr int R1 = (LOG2M == 9) ? 8 : 16, R2 = R1, R3 = M / (R1 * R2);
+    constexpr int LP = (LOG2M == 9) ? 3 : 4, MP = M + (M >> LP); // padded buffer (pad_idx)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
     const int nb = p.num_banks, dl = p.dct_len;
@@ -1224,9 +1235,9 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : 1024) k_front_reg(FrontPar
     const int dct_floats = (FUSED && p.dct) ? nb * dl : 0;
     const int dct_pad = (dct_floats + 3) & ~3;
     const int nb_pad = FUSED ? mel_scratch_floats(nb, p.cols) : 0;
-    float *s_wave = s_dct + dct_pad + wave * (2 * M + nb_pad);
+    float *s_wave = s_dct + dct_pad + wave * (2 * MP + nb_pad);
     float2 *buf = (float2 *)s_wave;
-    float *s_mel = s_wave + 2 * M;
+    float *s_mel = s_wave + 2 * MP;
 
     const float scale = p.scale; // 0.5 / W2, a power of two: folded into the window taps (exact)
     for (int i = tid; i < M; i += blockDim.x) {
@@ -1286,10 +1297,10 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : 1024) k_front_reg(FrontPar
                     for (int j = 0; j < NV; ++j) v[j] = t[j];
                 }
             }
-            stockham_pass<M, R1, M, true>(buf, s_tw, lane, v);
+            stockham_pass<M, R1, M, true, LP>(buf, s_tw, lane, v);
 #if !defined(MFX_REG_ABL) || MFX_REG_ABL < 2
-            stockham_pass<M, R2, M / R1, false>(buf, s_tw, lane, v);
-            stockham_pass<M, R3, R3, false>(buf, s_tw, lane, v);
+            stockham_pass<M, R2, M / R1, false, LP>(buf, s_tw, lane, v);
+            stockham_pass<M, R3, R3, false, LP>(buf, s_tw, lane, v);
 #endif
 
             // ---- real split over the bin pairs (k, M - k), k = lane + 64 j <= M/2, and the magnitudes
@@ -1298,7 +1309,7 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : 1024) k_front_reg(FrontPar
 #pragma unroll
             for (int j = 0; j <= NP; ++j) {
                 const int k = (j < NP) ? lane + 64 * j : M / 2;
-                const float2 zk = buf[k], zm = buf[(M - k) & (M - 1)];
+                const float2 zk = buf[pad_idx<LP>(k)], zm = buf[pad_idx<LP>((M - k) & (M - 1))];
                 const float sr = zk.x + zm.x, si = zk.y - zm.y;
                 const float dr = zk.x - zm.x, di = zk.y + zm.y;
                 const float2 w = s_cs[k];
@@ -1703,7 +1714,8 @@ size_t front_reg_lds_floats(const FrontParams &p, bool fused, int n_waves)
         f += 2 * ((M + 1 + 3) & ~(size_t)3) + ((p.num_banks + 2 + 3) & ~3);
         f += ((p.dct ? (size_t)p.num_banks * p.dct_len : 0) + 3) & ~(size_t)3;
     }
-    f += (size_t)n_waves * (2 * M + (fused ? mel_scratch_floats(p.num_banks, p.cols) : 0));
+    const size_t MP = M + (M >> (p.fft_size == 1024 ? 3 : 4)); // padded buffer (pad_idx)
+    f += (size_t)n_waves * (2 * MP + (fused ? mel_scratch_floats(p.num_banks, p.cols) : 0));
     return f;
 }
 
@@ -1711,7 +1723,8 @@ size_t front_reg_lds_floats(const FrontParams &p, bool fused, int n_waves)
 int front_reg_waves(const FrontParams &p, bool fused)
 {
     // (4096 points: 4 waves -- the kernel is built for 256 threads there, its 32 points per lane need the registers)
-    for (int nw = p.fft_size >= 4096 ? 4 : 16; nw >= 4; nw >>= 1)
+    // (2048 points fused: 8 waves -- its tables leave no room for more, and the build allows 256 registers there)
+    for (int nw = p.fft_size >= 4096 ? 4 : (p.fft_size == 2048 && fused) ? 8 : 16; nw >= 4; nw >>= 1)
         if (front_reg_lds_floats(p, fused, nw) * sizeof(float) <= 160 * 1024) return nw;
     return 0;
 }
@@ -1760,8 +1773,9 @@ hipError_t launch_front_generic(const FrontParams &p, bool fused, hipStream_t st
         const int nw = front_reg_waves(p, fused);
         if (nw == 0) return hipErrorInvalidValue;
         if (p.fft_size == 1024) return fused ? launch_reg<9, true>(p, nw, stream) : launch_reg<9, false>(p, nw, stream);
-        if (fused) return hipErrorInvalidValue; // callers fuse up to 1024 points only
-        return p.fft_size == 2048 ? launch_reg<10, false>(p, nw, stream) : launch_reg<11, false>(p, nw, stream);
+        if (p.fft_size == 2048) return fused ? launch_reg<10, true>(p, nw, stream) : launch_reg<10, false>(p, nw, stream);
+        if (fused) return hipErrorInvalidValue; // callers fuse up to 2048 points only
+        return launch_reg<11, false>(p, nw, stream);
     }
     const size_t lds = front_wave_lds_bytes(p, fused);
     const void *fn = fused ? (const void *)k_front_wave<true, 64> : (const void *)k_front_wave<false, 64>;
