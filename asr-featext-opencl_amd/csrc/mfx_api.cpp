@@ -68,7 +68,7 @@ struct mfx_handle {
     bool have_window = false;
 
     // tables in HBM
-    DevBuf<float> d_window, d_winpair, d_twid_pass, d_twid_half, d_twid_split, d_mel_w, d_dct;
+    DevBuf<float> d_window, d_winpair, d_twid_pass, d_twid_half, d_twid_split, d_twid_reg, d_mel_w, d_dct;
     DevBuf<int32_t> d_mel_beg;
     // 512-point kernel: per-lane mel plan + transposed DCT matrix
     DevBuf<float> d_mel_lane_w, d_dct_t, d_dct_lane_w;
@@ -211,6 +211,7 @@ void fill_front(const mfx_handle *h, FrontParams &p)
     p.winpair = h->d_winpair.p;
     p.twid_pass = h->d_twid_pass.p;
     p.twid_half = h->d_twid_half.p;
+    p.twid_reg = h->d_twid_reg.p;
     p.twid_split = h->d_twid_split.p;
     p.mel_w = h->d_mel_w.p;
     p.mel_beg = h->d_mel_beg.p;
@@ -333,6 +334,7 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_winpair.release();
     h->d_twid_pass.release();
     h->d_twid_half.release();
+    h->d_twid_reg.release();
     h->d_twid_split.release();
     h->d_mel_w.release();
     h->d_dct.release();
@@ -465,6 +467,27 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
             split[2 * k + 1] = -ws[2 * k];
         }
         if (upload(h->d_twid_split, split) != hipSuccess) return bail(MFX_ERR_DEVICE);
+        if (h->W2 >= 1024) {
+            // k_front_reg: per-pass twiddle tables laid out [k][butterfly] so that the lanes of one LDS read
+            // touch consecutive words.  Pass 1 (radix R1 over M points): W_M^(pp k), pp < M/R1; pass 2 (radix R1
+            // over M/R1 points): W_M^(pp k R1), pp < M/R1^2.  Same values as the W_M^e table above.
+            const int M = h->W2 / 2, R1 = h->W2 == 1024 ? 8 : 16, n1 = M / R1, n2 = M / (R1 * R1);
+            std::vector<float> reg((size_t)2 * (R1 - 1) * (n1 + n2));
+            size_t o = 0;
+            for (int k = 1; k < R1; ++k)
+                for (int pp = 0; pp < n1; ++pp, ++o) {
+                    const int e = (pp * k) & (M - 1);
+                    reg[2 * o] = tw[2 * e];
+                    reg[2 * o + 1] = tw[2 * e + 1];
+                }
+            for (int k = 1; k < R1; ++k)
+                for (int pp = 0; pp < n2; ++pp, ++o) {
+                    const int e = (pp * k * R1) & (M - 1);
+                    reg[2 * o] = tw[2 * e];
+                    reg[2 * o + 1] = tw[2 * e + 1];
+                }
+            if (upload(h->d_twid_reg, reg) != hipSuccess) return bail(MFX_ERR_DEVICE);
+        }
         if (h->fast512) {
             std::vector<float> full;
             build_twiddles(256, 256, full); // W_256^e

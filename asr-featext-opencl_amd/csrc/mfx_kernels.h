@@ -66,6 +66,7 @@ struct FrontParams {
     const float *winpair;     // [16][16][2] window laid out per lane  (512 fast path)
     const float *twid_pass;   // [16][16][2] W_256^(l*k)               (512 fast path)
     const float *twid_half;   // [W2/2][2]   W_{W2/2}^k, k < W2/2       (generic Stockham, radix 4 needs 3k)
+    const float *twid_reg;    // k_front_reg: pass tables [R1-1][M/R1][2] then [R1-1][M/R1^2][2] (W2 >= 1024)
     const float *twid_split;  // [W2/2+1][2] -i * W_{W2}^k             (real split)
     const float *mel_w;       // [2][W2]
     const int32_t *mel_beg;   // [nb+2]

@@ -1185,6 +1185,7 @@ __device__ __forceinline__ int pad_idx(int i)
     return i + (i >> LP);
 }
 
+// s_tw: this pass's twiddles W_LEN^(pp k) laid out [k - 1][pp], pp < LEN / R (unused by the last pass)
 template <int M, int R, int LEN, bool FROM_REGS, int LP>
 __device__ __forceinline__ void stockham_pass(float2 *buf, const float2 *s_tw, int lane, float2 (&v)[M / 64])
 {
@@ -1208,7 +1209,7 @@ __device__ __forceinline__ void stockham_pass(float2 *buf, const float2 *s_tw, i
 #pragma unroll
         for (int k = 1; k < R; ++k)
             buf[pad_idx<LP>(q + ST * (R * pp + k))] =
-                (LEN == R) ? w[k] : cmul(w[k], s_tw[(pp * k * ST) & (M - 1)]); // W_LEN^(pp k)
+                (LEN == R) ? w[k] : cmul(w[k], s_tw[(k - 1) * N1 + pp]); // W_LEN^(pp k)
     }
     wave_sync();
 }
@@ -1223,7 +1224,8 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
     const int nb = p.num_banks, dl = p.dct_len;
     // shared tables, then one buffer of M complex points (+ mel scratch) per wave
-    float2 *s_tw = (float2 *)smem;                 // [M]   W_M^k
+    constexpr int NT1 = (R1 - 1) * (M / R1), NT2 = (R2 - 1) * (M / (R1 * R2));
+    float2 *s_tw = (float2 *)smem;                 // pass 1 [R1-1][M/R1], then pass 2 [R2-1][M/(R1 R2)]; M slots reserved
     float2 *s_cs = s_tw + M;                       // [M/2 + 1]  -i W_{2M}^k (one per bin pair), padded to even
     float2 *s_win = s_cs + (M / 2 + 2);            // [M]   (w[2n], w[2n+1]) * 0.5 / W2
     float *s_w0 = (float *)(s_win + M);
@@ -1240,8 +1242,9 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
     float *s_mel = s_wave + 2 * MP;
 
     const float scale = p.scale; // 0.5 / W2, a power of two: folded into the window taps (exact)
+    static_assert(NT1 + NT2 <= M, "pass tables fit the reserved slots");
     for (int i = tid; i < M; i += blockDim.x) {
-        s_tw[i] = ((const float2 *)p.twid_half)[i];
+        if (i < NT1 + NT2) s_tw[i] = ((const float2 *)p.twid_reg)[i];
         const float2 wv = ((const float2 *)p.window)[i];
         s_win[i] = make_float2(wv.x * scale, wv.y * scale);
     }
@@ -1299,7 +1302,7 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
             }
             stockham_pass<M, R1, M, true, LP>(buf, s_tw, lane, v);
 #if !defined(MFX_REG_ABL) || MFX_REG_ABL < 2
-            stockham_pass<M, R2, M / R1, false, LP>(buf, s_tw, lane, v);
+            stockham_pass<M, R2, M / R1, false, LP>(buf, s_tw + NT1, lane, v);
             stockham_pass<M, R3, R3, false, LP>(buf, s_tw, lane, v);
 #endif
 
