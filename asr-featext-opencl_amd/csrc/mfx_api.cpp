@@ -69,7 +69,8 @@ struct mfx_handle {
 
     // tables in HBM
     DevBuf<float> d_window, d_winpair, d_twid_pass, d_twid_half, d_twid_split, d_twid_reg, d_mel_w, d_dct;
-    DevBuf<int32_t> d_mel_beg;
+    DevBuf<int32_t> d_mel_beg, d_mel_items, d_mel_pieces;
+    int mel_K = 0;
     // 512-point kernel: per-lane mel plan + transposed DCT matrix
     DevBuf<float> d_mel_lane_w, d_dct_t, d_dct_lane_w;
     int dct_lane_stride = 0;
@@ -98,7 +99,8 @@ struct mfx_handle {
     int sweep_cap = 0;                    // alphas the sweep buffers hold
     int sweep_n = 0;                      // alphas of the last sweep (0: last apply was a plain one)
     DevBuf<float> d_sweep_w, d_sweep_src, d_sweep_blk, d_sweep_stats;
-    DevBuf<int32_t> d_sweep_beg;
+    DevBuf<int32_t> d_sweep_beg, d_sweep_items, d_sweep_pieces;
+    int sweep_K = 0;
     DevBuf<Segment> d_sweep_segs;         // [2][sweep_cap]: rows with context, rows delivered
 
     // batch plan
@@ -181,6 +183,13 @@ int refresh_mel(mfx_handle *h)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, upload(h->d_mel_w, t.weights));
     HIP_TRY(h, upload(h->d_mel_beg, t.beg));
+    {
+        MelItemPlan ip;
+        build_mel_item_plan(t.beg, h->nb, ip);
+        HIP_TRY(h, upload(h->d_mel_items, ip.items));
+        HIP_TRY(h, upload(h->d_mel_pieces, ip.pieces));
+        h->mel_K = ip.K;
+    }
     h->fused_ok = false;
     if (h->fast512 && build_mel_lane_plan(t, h->nb, h->W2, /*max_read_bin=*/511 - 32, h->plan)) {
         HIP_TRY(h, upload(h->d_mel_lane_w, h->plan.w));
@@ -215,6 +224,9 @@ void fill_front(const mfx_handle *h, FrontParams &p)
     p.twid_split = h->d_twid_split.p;
     p.mel_w = h->d_mel_w.p;
     p.mel_beg = h->d_mel_beg.p;
+    p.mel_items = h->d_mel_items.p;
+    p.mel_pieces = h->d_mel_pieces.p;
+    p.mel_K = h->mel_K;
     p.dct = h->ceps > 0 ? h->d_dct.p : nullptr;
     p.num_banks = h->nb;
     p.dct_len = h->dl;
@@ -339,6 +351,10 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_mel_w.release();
     h->d_dct.release();
     h->d_mel_beg.release();
+    h->d_mel_items.release();
+    h->d_mel_pieces.release();
+    h->d_sweep_items.release();
+    h->d_sweep_pieces.release();
     h->d_mel_lane_w.release();
     h->d_dct_t.release();
     h->d_dct_lane_w.release();
@@ -792,6 +808,8 @@ int prepare_sweep(mfx_handle *h, const float *alphas, int n)
     if (same && n <= h->sweep_cap && !h->sweep_alphas.empty()) return MFX_OK;
     std::vector<float> w(wstride * n);
     std::vector<int32_t> b(bstride * n);
+    std::vector<MelItemPlan> plans((size_t)n);
+    int K = 1;
     for (int a = 0; a < n; ++a) {
         MelTable t;
         build_mel_table(h->nb, h->W2, h->cfg.sample_rate, h->cfg.low_freq, h->cfg.high_freq, alphas[a], t);
@@ -799,10 +817,23 @@ int prepare_sweep(mfx_handle *h, const float *alphas, int n)
             if (v < 0 || v > h->W2 / 2) return fail(h, MFX_ERR_CONFIG, "mel filter edge outside [0, fft_size/2]");
         std::copy(t.weights.begin(), t.weights.end(), w.begin() + wstride * a);
         std::copy(t.beg.begin(), t.beg.end(), b.begin() + bstride * a);
+        build_mel_item_plan(t.beg, h->nb, plans[a]);
+        K = std::max(K, plans[a].K);
+    }
+    // one item table per alpha, all padded to the longest plan (idle entries have slot -1)
+    std::vector<int32_t> items((size_t)n * K * 256, 0), pieces((size_t)n * h->nb);
+    for (int a = 0; a < n; ++a) {
+        int32_t *dst = &items[(size_t)a * K * 256];
+        for (int i = 0; i < K * 64; ++i) dst[4 * i] = -1;
+        std::copy(plans[a].items.begin(), plans[a].items.end(), dst);
+        std::copy(plans[a].pieces.begin(), plans[a].pieces.end(), pieces.begin() + (size_t)a * h->nb);
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(h->d_sweep_w.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_sweep_beg.p, b.data(), b.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(h, upload(h->d_sweep_items, items));
+    HIP_TRY(h, upload(h->d_sweep_pieces, pieces));
+    h->sweep_K = K;
     h->sweep_alphas.assign(alphas, alphas + n);
     return MFX_OK;
 }
@@ -854,6 +885,11 @@ int apply_impl(mfx_handle *h, const float *alphas, int n_alpha)
     mp.fft_size = h->W2;
     mp.mel_w = sweep ? h->d_sweep_w.p : h->d_mel_w.p;
     mp.mel_beg = sweep ? h->d_sweep_beg.p : h->d_mel_beg.p;
+    mp.mel_items = sweep ? h->d_sweep_items.p : h->d_mel_items.p;
+    mp.mel_pieces = sweep ? h->d_sweep_pieces.p : h->d_mel_pieces.p;
+    mp.mel_K = sweep ? h->sweep_K : h->mel_K;
+    mp.mel_items_stride = mp.mel_K * 256;
+    mp.mel_pieces_stride = h->nb;
     mp.dct = h->ceps > 0 ? h->d_dct.p : nullptr;
     mp.num_banks = h->nb;
     mp.dct_len = h->dl;
@@ -1325,6 +1361,9 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
             mp.fft_size = h->W2;
             mp.mel_w = h->d_mel_w.p;
             mp.mel_beg = h->d_mel_beg.p;
+            mp.mel_items = h->d_mel_items.p;
+            mp.mel_pieces = h->d_mel_pieces.p;
+            mp.mel_K = h->mel_K;
             mp.dct = h->ceps > 0 ? h->d_dct.p : nullptr;
             mp.num_banks = h->nb;
             mp.dct_len = h->dl;

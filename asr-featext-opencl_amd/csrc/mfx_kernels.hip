@@ -90,14 +90,17 @@ __device__ __forceinline__ void fft16(float2 (&x)[16])
 // ascending m (mfcccpu.cpp:222-232).  Tables are read from LDS copies (s_*).
 // ------------------------------------------------------------------------------------------------
 // LDS floats of the scratch behind `melbuf`: the log mel energies + the partial sums of the chunked DCT
-__host__ __device__ inline int mel_scratch_floats(int nb, int cols) { return ((nb + 3) & ~3) + 8 * ((cols + 3) & ~3); }
+__host__ __device__ inline int mel_scratch_floats(int nb, int cols) { return ((nb + 3) & ~3) + 8 * ((cols + 3) & ~3) + 4 * nb; }
+// block-shared LDS words of the mel work plan: items [K][64][4] + pieces [nb]
+__host__ __device__ inline int mel_plan_words(int nb, int K) { return K * 256 + ((nb + 3) & ~3); }
 
-// walk one filter's bins in ascending order, 8 bins per trip (the 16 LDS reads are issued together)
+// Walk the bins [b0, b1) of one filter piece in ascending order, 8 bins per trip: the 16 LDS reads of a trip
+// are issued together; bins past b1 are read (the buffers extend at least 8 words past any bin) and
+// discarded by a select, so there is no scalar remainder loop with its dependent read latencies.
 __device__ __forceinline__ float mel_filter_sum(const float *w, const float *mag, int b0, int b1)
 {
     float acc = 0.f;
-    int k = b0;
-    for (; k + 8 <= b1; k += 8) {
+    for (int k = b0; k < b1; k += 8) {
         float wv[8], mv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -105,75 +108,98 @@ __device__ __forceinline__ float mel_filter_sum(const float *w, const float *mag
             mv[u] = mag[k + u];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += wv[u] * mv[u];
+        for (int u = 0; u < 8; ++u) acc += (k + u < b1) ? wv[u] * mv[u] : 0.f;
     }
-    for (; k < b1; ++k) acc += w[k] * mag[k];
     return acc;
 }
 
 template <int G>
 __device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int g, const float *s_w0,
-                                            const float *s_w1, const int *s_beg, const float *s_dct, int nb,
-                                            int dct_len, int cols, float *out_row)
+                                            const float *s_w1, const int4 *s_items, const int *s_pieces, int K,
+                                            const float *s_dct, int nb, int dct_len, int cols, float *out_row)
 {
     static_assert(G == 64, "one wave per frame");
-    // Mel filters are narrow at the bottom and wide at the top of the band: lane i takes filter i AND
-    // filter nb-1-i, so every lane walks about the same number of bins (each filter still sums its own
-    // bins in ascending order, as the reference).
-    const int half = (nb + 1) >> 1;
-    for (int i = g; i < half; i += G) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int m = t == 0 ? i : nb - 1 - i;
-            if (t == 1 && m == i) break; // the middle filter of an odd bank
-            const float acc = mel_filter_sum((m & 1) ? s_w1 : s_w0, mag, s_beg[m], s_beg[m + 2]);
-            melbuf[m] = logf(fmaxf(acc, 1e-30f));
-        }
+    // Mel filters are narrow at the bottom and wide at the top of the band.  Their bin ranges are cut into
+    // <= 4 pieces each and the pieces dealt to the lanes by the host (MelItemPlan) so that every lane walks
+    // about the same number of bins; a piece is summed in ascending bin order, a filter's pieces are added in
+    // ascending order (mfcccpu.cpp:206-215 sums the whole range in one chain: same terms, the association
+    // differs at the piece boundaries only).
+    float *mpart = melbuf + ((nb + 3) & ~3) + 8 * ((cols + 3) & ~3); // [nb][4]
+#if !defined(MFX_MEL_ABL) || MFX_MEL_ABL != 1
+    for (int k = 0; k < K; ++k) {
+        const int4 it = s_items[k * 64 + g];
+        if (it.x >= 0) mpart[it.x] = mel_filter_sum(((it.x >> 2) & 1) ? s_w1 : s_w0, mag, it.y, it.z);
+    }
+#endif
+    wave_sync();
+    for (int m = g; m < nb; m += G) {
+        float acc = mpart[4 * m];
+        const int n = s_pieces[m];
+        for (int s2 = 1; s2 < n; ++s2) acc += mpart[4 * m + s2];
+        melbuf[m] = logf(fmaxf(acc, 1e-30f));
     }
     wave_sync();
+#if defined(MFX_MEL_ABL) && MFX_MEL_ABL == 2
+    for (int c = g; c < cols; c += G) out_row[c] = melbuf[c];
+    return;
+#endif
+#if defined(MFX_MEL_ABL) && MFX_MEL_ABL == 3
+    for (int c = g; c < cols; c += G) out_row[c] = mag[c];
+    return;
+#endif
     if (s_dct) {
-        // DCT: out[c] = sum_m mel[m] * dct[m][c].  The m range is cut into n_ch chunks so that the (column,
-        // chunk) items fill the 64 lanes; a chunk is summed in ascending m, the chunks are added in
+        // DCT: out[c] = sum_m mel[m] * dct[m][c].  A work item is 4 consecutive columns over one chunk of the m
+        // range (one mel read + one 16-byte row read feed 4 multiply-adds); the chunk count n_ch is chosen so
+        // that the items fill the 64 lanes.  A chunk is summed in ascending m, the chunks are added in
         // ascending order by the column's lane (mfcccpu.cpp:222-232 sums m = 0..nb-1 in one chain: same
-        // terms, association differs by the chunk boundaries only).
+        // terms, association differs by the chunk boundaries only).  s_dct rows are padded to dl4 floats.
+        const int dl4 = (dct_len + 3) & ~3, quads = (cols + 3) >> 2, cols4 = quads * 4;
         int n_ch = 1, best = nb; // cost ~ rounds * terms per item
         for (int c2 = 2; c2 <= 8; c2 <<= 1) {
-            const int cost = ((cols * c2 + G - 1) / G) * ((nb + c2 - 1) / c2);
+            const int cost = ((quads * c2 + G - 1) / G) * ((nb + c2 - 1) / c2);
             if (cost < best) {
                 best = cost;
                 n_ch = c2;
             }
         }
-        const int ch_len = (nb + n_ch - 1) / n_ch, cols4 = (cols + 3) & ~3;
+        const int ch_len = (nb + n_ch - 1) / n_ch;
         float *part = melbuf + ((nb + 3) & ~3); // [n_ch][cols4]
-        for (int it = g; it < cols * n_ch; it += G) {
-            const int ch = it / cols, c = it - ch * cols;
+        for (int it = g; it < quads * n_ch; it += G) {
+            const int ch = it / quads, q = it - ch * quads;
             const int m0 = ch * ch_len, m1 = min(nb, m0 + ch_len);
-            float acc = 0.f;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int m = m0;
-            for (; m + 8 <= m1; m += 8) { // reads batched 8 deep
-                float ev[8], dv[8];
+            for (; m + 4 <= m1; m += 4) { // reads batched 4 deep
+                float ev[4];
+                float4 dv[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 4; ++u) {
                     ev[u] = melbuf[m + u];
-                    dv[u] = s_dct[(m + u) * dct_len + c];
+                    dv[u] = *(const float4 *)(s_dct + (m + u) * dl4 + 4 * q);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc += ev[u] * dv[u];
+                for (int u = 0; u < 4; ++u) {
+                    acc.x += ev[u] * dv[u].x;
+                    acc.y += ev[u] * dv[u].y;
+                    acc.z += ev[u] * dv[u].z;
+                    acc.w += ev[u] * dv[u].w;
+                }
             }
-            for (; m < m1; ++m) acc += melbuf[m] * s_dct[m * dct_len + c];
-            if (n_ch == 1)
-                out_row[c] = acc;
-            else
-                part[ch * cols4 + c] = acc;
+            for (; m < m1; ++m) {
+                const float e = melbuf[m];
+                const float4 d = *(const float4 *)(s_dct + m * dl4 + 4 * q);
+                acc.x += e * d.x;
+                acc.y += e * d.y;
+                acc.z += e * d.z;
+                acc.w += e * d.w;
+            }
+            *(float4 *)(part + ch * cols4 + 4 * q) = acc;
         }
-        if (n_ch > 1) {
-            wave_sync();
-            for (int c = g; c < cols; c += G) {
-                float acc = part[c];
-                for (int ch = 1; ch < n_ch; ++ch) acc += part[ch * cols4 + c];
-                out_row[c] = acc;
-            }
+        wave_sync();
+        for (int c = g; c < cols; c += G) {
+            float acc = part[c];
+            for (int ch = 1; ch < n_ch; ++ch) acc += part[ch * cols4 + c];
+            out_row[c] = acc;
         }
     } else {
         for (int c = g; c < cols; c += G) out_row[c] = melbuf[c];
@@ -1008,11 +1034,12 @@ __global__ void __launch_bounds__(256) k_front_wave(FrontParams p)
     // shared tables (FUSED only), then per wave: two complex buffers of M points + mel scratch
     float *s_w0 = smem;
     float *s_w1 = s_w0 + (FUSED ? bins_pad : 0);
-    int *s_beg = (int *)(s_w1 + (FUSED ? bins_pad : 0));
-    const int beg_pad = FUSED ? ((nb + 2 + 3) & ~3) : 0;
-    float *s_dct = (float *)(s_beg + beg_pad);
-    const int dct_floats = (FUSED && p.dct) ? nb * dl : 0;
-    const int dct_pad = (dct_floats + 3) & ~3;
+    int4 *s_items = (int4 *)(s_w1 + (FUSED ? bins_pad : 0)); // mel work plan: items [K][64], then pieces [nb]
+    int *s_pieces = (int *)s_items + p.mel_K * 256;
+    float *s_dct = (float *)((int *)s_items + (FUSED ? mel_plan_words(nb, p.mel_K) : 0));
+    const int dl4 = (dl + 3) & ~3;               // DCT rows padded to whole 16-byte words in LDS
+    const int dct_floats = (FUSED && p.dct) ? nb * dl4 : 0;
+    const int dct_pad = dct_floats;
     const int nb_pad = FUSED ? mel_scratch_floats(nb, p.cols) : 0;
     float *s_wave = s_dct + dct_pad + wave * (4 * M + nb_pad);
     float2 *bufA = (float2 *)s_wave;
@@ -1023,8 +1050,12 @@ __global__ void __launch_bounds__(256) k_front_wave(FrontParams p)
             s_w0[i] = p.mel_w[i];
             s_w1[i] = p.mel_w[W2 + i];
         }
-        for (int i = tid; i < nb + 2; i += 256) s_beg[i] = p.mel_beg[i];
-        for (int i = tid; i < dct_floats; i += 256) s_dct[i] = p.dct[i];
+        for (int i = tid; i < p.mel_K * 256; i += 256) ((int *)s_items)[i] = p.mel_items[i];
+        for (int i = tid; i < nb; i += 256) s_pieces[i] = p.mel_pieces[i];
+        for (int i = tid; i < dct_floats; i += 256) {
+            const int m = i / dl4, c = i - m * dl4;
+            s_dct[i] = c < dl ? p.dct[m * dl + c] : 0.f;
+        }
     }
     __syncthreads();
 
@@ -1117,7 +1148,7 @@ __global__ void __launch_bounds__(256) k_front_wave(FrontParams p)
             }
             group_sync();
             if (FUSED) {
-                mel_log_dct<G>(mag, s_mel, lane, s_w0, s_w1, s_beg, p.dct ? s_dct : nullptr, nb, dl, p.cols,
+                mel_log_dct<G>(mag, s_mel, lane, s_w0, s_w1, s_items, s_pieces, p.mel_K, p.dct ? s_dct : nullptr, nb, dl, p.cols,
                                 p.feat + (ch.out_row + f) * (int64_t)p.feat_pitch);
                 group_sync();
             }
@@ -1231,11 +1262,12 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
     float *s_w0 = (float *)(s_win + M);
     constexpr int bins_pad = (M + 1 + 3) & ~3;
     float *s_w1 = s_w0 + (FUSED ? bins_pad : 0);
-    int *s_beg = (int *)(s_w1 + (FUSED ? bins_pad : 0));
-    const int beg_pad = FUSED ? ((nb + 2 + 3) & ~3) : 0;
-    float *s_dct = (float *)(s_beg + beg_pad);
-    const int dct_floats = (FUSED && p.dct) ? nb * dl : 0;
-    const int dct_pad = (dct_floats + 3) & ~3;
+    int4 *s_items = (int4 *)(s_w1 + (FUSED ? bins_pad : 0)); // mel work plan: items [K][64], then pieces [nb]
+    int *s_pieces = (int *)s_items + p.mel_K * 256;
+    float *s_dct = (float *)((int *)s_items + (FUSED ? mel_plan_words(nb, p.mel_K) : 0));
+    const int dl4 = (dl + 3) & ~3;               // DCT rows padded to whole 16-byte words in LDS
+    const int dct_floats = (FUSED && p.dct) ? nb * dl4 : 0;
+    const int dct_pad = dct_floats;
     const int nb_pad = FUSED ? mel_scratch_floats(nb, p.cols) : 0;
     float *s_wave = s_dct + dct_pad + wave * (2 * MP + nb_pad);
     float2 *buf = (float2 *)s_wave;
@@ -1254,8 +1286,12 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
             s_w0[i] = p.mel_w[i];
             s_w1[i] = p.mel_w[W2 + i];
         }
-        for (int i = tid; i < nb + 2; i += blockDim.x) s_beg[i] = p.mel_beg[i];
-        for (int i = tid; i < dct_floats; i += blockDim.x) s_dct[i] = p.dct[i];
+        for (int i = tid; i < p.mel_K * 256; i += blockDim.x) ((int *)s_items)[i] = p.mel_items[i];
+        for (int i = tid; i < nb; i += blockDim.x) s_pieces[i] = p.mel_pieces[i];
+        for (int i = tid; i < dct_floats; i += blockDim.x) {
+            const int m = i / dl4, c = i - m * dl4;
+            s_dct[i] = c < dl ? p.dct[m * dl + c] : 0.f;
+        }
     }
     __syncthreads();
 
@@ -1335,7 +1371,7 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
 #if defined(MFX_REG_ABL) && MFX_REG_ABL >= 1
                 if (lane < p.cols) p.feat[(ch.out_row + f) * (int64_t)p.feat_pitch + lane] = mag[lane];
 #else
-                mel_log_dct<64>(mag, s_mel, lane, s_w0, s_w1, s_beg, p.dct ? s_dct : nullptr, nb, dl, p.cols,
+                mel_log_dct<64>(mag, s_mel, lane, s_w0, s_w1, s_items, s_pieces, p.mel_K, p.dct ? s_dct : nullptr, nb, dl, p.cols,
                                 p.feat + (ch.out_row + f) * (int64_t)p.feat_pitch);
 #endif
                 wave_sync();
@@ -1365,32 +1401,38 @@ __global__ void __launch_bounds__(256) k_melcep(MelcepParams p)
     const int nb = p.num_banks, dl = p.dct_len;
     float *s_w0 = smem;
     float *s_w1 = s_w0 + bins_pad;
-    int *s_beg = (int *)(s_w1 + bins_pad);
-    const int beg_pad = (nb + 2 + 3) & ~3;
-    float *s_dct = (float *)(s_beg + beg_pad);
-    const int dct_floats = p.dct ? nb * dl : 0;
-    const int dct_pad = (dct_floats + 3) & ~3;
+    int4 *s_items = (int4 *)(s_w1 + bins_pad); // mel work plan: items [K][64], then pieces [nb]
+    int *s_pieces = (int *)s_items + p.mel_K * 256;
+    float *s_dct = (float *)((int *)s_items + mel_plan_words(nb, p.mel_K));
+    const int dl4 = (dl + 3) & ~3;               // DCT rows padded to whole 16-byte words in LDS
+    const int dct_floats = p.dct ? nb * dl4 : 0;
+    const int dct_pad = dct_floats;
     const int nb_pad = mel_scratch_floats(nb, p.cols);
     float *s_mag = s_dct + dct_pad + wave * (bins_pad + nb_pad);
     float *s_mel = s_mag + bins_pad;
 
     // blockIdx.y = filterbank of a VTLN sweep (one table per alpha over the same spectrum)
     const float *mel_w = p.mel_w + (int64_t)blockIdx.y * p.mel_w_stride;
-    const int32_t *mel_beg = p.mel_beg + (int64_t)blockIdx.y * p.mel_beg_stride;
+    const int32_t *mel_items = p.mel_items + (int64_t)blockIdx.y * p.mel_items_stride;
+    const int32_t *mel_pieces = p.mel_pieces + (int64_t)blockIdx.y * p.mel_pieces_stride;
     float *feat = p.feat + (int64_t)blockIdx.y * p.feat_table_stride;
     for (int i = tid; i < nbins; i += 256) {
         s_w0[i] = mel_w[i];
         s_w1[i] = mel_w[W2 + i];
     }
-    for (int i = tid; i < nb + 2; i += 256) s_beg[i] = mel_beg[i];
-    for (int i = tid; i < dct_floats; i += 256) s_dct[i] = p.dct[i];
+    for (int i = tid; i < p.mel_K * 256; i += 256) ((int *)s_items)[i] = mel_items[i];
+    for (int i = tid; i < nb; i += 256) s_pieces[i] = mel_pieces[i];
+    for (int i = tid; i < dct_floats; i += 256) {
+        const int m = i / dl4, c = i - m * dl4;
+        s_dct[i] = c < dl ? p.dct[m * dl + c] : 0.f;
+    }
     __syncthreads();
 
     for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < p.n_rows; r += (int64_t)gridDim.x * 4) {
         const float *src = p.spec + r * p.spec_pitch;
         for (int k = lane; k < nbins; k += 64) s_mag[k] = src[k];
         wave_sync();
-        mel_log_dct<64>(s_mag, s_mel, lane, s_w0, s_w1, s_beg, p.dct ? s_dct : nullptr, nb, dl, p.cols,
+        mel_log_dct<64>(s_mag, s_mel, lane, s_w0, s_w1, s_items, s_pieces, p.mel_K, p.dct ? s_dct : nullptr, nb, dl, p.cols,
                         feat + r * p.feat_pitch);
         wave_sync();
     }
@@ -1714,8 +1756,8 @@ size_t front_reg_lds_floats(const FrontParams &p, bool fused, int n_waves)
     const size_t M = (size_t)p.fft_size >> 1;
     size_t f = 2 * M + 2 * (M / 2 + 2) + 2 * M; // pass twiddles, split twiddles, window pairs
     if (fused) {
-        f += 2 * ((M + 1 + 3) & ~(size_t)3) + ((p.num_banks + 2 + 3) & ~3);
-        f += ((p.dct ? (size_t)p.num_banks * p.dct_len : 0) + 3) & ~(size_t)3;
+        f += 2 * ((M + 1 + 3) & ~(size_t)3) + mel_plan_words(p.num_banks, p.mel_K);
+        f += p.dct ? (size_t)p.num_banks * ((p.dct_len + 3) & ~3) : 0;
     }
     const size_t MP = M + (M >> (p.fft_size == 1024 ? 3 : 4)); // padded buffer (pad_idx)
     f += (size_t)n_waves * (2 * MP + (fused ? mel_scratch_floats(p.num_banks, p.cols) : 0));
@@ -1762,8 +1804,8 @@ size_t front_wave_lds_bytes(const FrontParams &p, bool fused)
     const int M = p.fft_size >> 1, nbins = M + 1, bins_pad = (nbins + 3) & ~3;
     size_t f = 0;
     if (fused) {
-        f += 2 * (size_t)bins_pad + ((p.num_banks + 2 + 3) & ~3);
-        f += ((p.dct ? (size_t)p.num_banks * p.dct_len : 0) + 3) & ~(size_t)3;
+        f += 2 * (size_t)bins_pad + mel_plan_words(p.num_banks, p.mel_K);
+        f += p.dct ? (size_t)p.num_banks * ((p.dct_len + 3) & ~3) : 0;
     }
     f += 4 * ((size_t)4 * M + (fused ? mel_scratch_floats(p.num_banks, p.cols) : 0));
     return f * sizeof(float);
@@ -1801,7 +1843,7 @@ hipError_t launch_melcep(const MelcepParams &p, hipStream_t stream)
     if (p.n_rows <= 0) return hipSuccess;
     const int nbins = (p.fft_size >> 1) + 1, bins_pad = (nbins + 3) & ~3;
     const int nb = p.num_banks;
-    size_t f = 2 * bins_pad + ((nb + 2 + 3) & ~3) + (((p.dct ? nb * p.dct_len : 0) + 3) & ~3) +
+    size_t f = 2 * bins_pad + mel_plan_words(nb, p.mel_K) + (p.dct ? nb * ((p.dct_len + 3) & ~3) : 0) +
                4 * (bins_pad + mel_scratch_floats(nb, p.cols));
     const size_t lds = f * sizeof(float);
     if (lds > 64 * 1024) {

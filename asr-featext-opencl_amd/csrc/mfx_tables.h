@@ -68,4 +68,16 @@ void build_dct_lane_rows(const MelLanePlan &plan, const std::vector<float> &dct,
 void build_dct_transposed(const std::vector<float> &dct, int num_banks, int dct_len, int &stride, int &nb_pad,
                           std::vector<float> &out);
 
+// Work plan of the wave-per-frame mel stage (mel_log_dct): every filter's bin range is cut into <= 4
+// consecutive pieces of <= ~16 bins, the pieces are dealt to the 64 lanes so that all lanes walk about the
+// same number of bins (longest piece first, to the least loaded lane).
+//   items  : [K][64][4] = {slot, first bin, end bin, 0}; slot = 4 * filter + piece, or -1 for an idle entry
+//   pieces : [num_banks] number of pieces of each filter (its partial sums are added in ascending order)
+struct MelItemPlan {
+    int K = 0;
+    std::vector<int32_t> items;
+    std::vector<int32_t> pieces;
+};
+void build_mel_item_plan(const std::vector<int32_t> &beg, int num_banks, MelItemPlan &out);
+
 } // namespace mfx
