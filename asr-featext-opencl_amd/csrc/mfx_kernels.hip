@@ -125,12 +125,10 @@ __device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int
     // ascending order (mfcccpu.cpp:206-215 sums the whole range in one chain: same terms, the association
     // differs at the piece boundaries only).
     float *mpart = melbuf + ((nb + 3) & ~3) + 8 * ((cols + 3) & ~3); // [nb][4]
-#if !defined(MFX_MEL_ABL) || MFX_MEL_ABL != 1
     for (int k = 0; k < K; ++k) {
         const int4 it = s_items[k * 64 + g];
         if (it.x >= 0) mpart[it.x] = mel_filter_sum(((it.x >> 2) & 1) ? s_w1 : s_w0, mag, it.y, it.z);
     }
-#endif
     wave_sync();
     for (int m = g; m < nb; m += G) {
         float acc = mpart[4 * m];
@@ -139,14 +137,6 @@ __device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int
         melbuf[m] = logf(fmaxf(acc, 1e-30f));
     }
     wave_sync();
-#if defined(MFX_MEL_ABL) && MFX_MEL_ABL == 2
-    for (int c = g; c < cols; c += G) out_row[c] = melbuf[c];
-    return;
-#endif
-#if defined(MFX_MEL_ABL) && MFX_MEL_ABL == 3
-    for (int c = g; c < cols; c += G) out_row[c] = mag[c];
-    return;
-#endif
     if (s_dct) {
         // DCT: out[c] = sum_m mel[m] * dct[m][c].  A work item is 4 consecutive columns over one chunk of the m
         // range (one mel read + one 16-byte row read feed 4 multiply-adds); the chunk count n_ch is chosen so
@@ -613,9 +603,6 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
     // the slots are read (times zero weights) before every word has been written once: make them finite
     for (int i = lane; i < 4 * kSlot; i += 64) s_wave[i] = 0.f;
     __syncthreads();
-#ifdef MFX_IDLE_WAVES   // dev-only experiment: the block's last waves take no front-end work
-    if (wave >= kWaves - MFX_IDLE_WAVES) return;
-#endif
 
     // ---- FUSE: the delta wave.  It consumes the block's tiles in order; a tile is ready once the
     // chunks it reads (its own rows and up to D rows either side) have their bits set in s_done.  The
@@ -1337,10 +1324,8 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
                 }
             }
             stockham_pass<M, R1, M, true, LP>(buf, s_tw, lane, v);
-#if !defined(MFX_REG_ABL) || MFX_REG_ABL < 2
             stockham_pass<M, R2, M / R1, false, LP>(buf, s_tw + NT1, lane, v);
             stockham_pass<M, R3, R3, false, LP>(buf, s_tw, lane, v);
-#endif
 
             // ---- real split over the bin pairs (k, M - k), k = lane + 64 j <= M/2, and the magnitudes
             constexpr int NP = M / 128; // pairs per lane (+ the self-paired k = M/2 on lane 0)
@@ -1368,12 +1353,8 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
                 }
                 if (lane == 0) mag[M / 2] = mag_lo[NP];
                 wave_sync();
-#if defined(MFX_REG_ABL) && MFX_REG_ABL >= 1
-                if (lane < p.cols) p.feat[(ch.out_row + f) * (int64_t)p.feat_pitch + lane] = mag[lane];
-#else
                 mel_log_dct<64>(mag, s_mel, lane, s_w0, s_w1, s_items, s_pieces, p.mel_K, p.dct ? s_dct : nullptr, nb, dl, p.cols,
                                 p.feat + (ch.out_row + f) * (int64_t)p.feat_pitch);
-#endif
                 wave_sync();
             } else {
                 float *dst = p.spec + (ch.out_row + f) * (int64_t)p.spec_pitch;

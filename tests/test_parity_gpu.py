@@ -459,6 +459,22 @@ def test_c2_full_size_properties(pkg, orc):
 # the C++ mirror (class MfccHip : MfccBase) and the afet-style driver built on it
 # ---------------------------------------------------------------------------------------------
 
+@pytest.mark.parametrize("W,S,fft", [(2400, 960, 4096), (3000, 1001, 4096), (1024, 256, 1024), (2048, 512, 2048)])
+def test_long_transforms_register_kernel(pkg, orc, W, S, fft):
+    """k_front_reg at its three sizes, full-length windows (no zero padding inside the transform), even and odd
+    shifts (paired 32-bit loads vs single samples), batch (fused up to 2048 points, spectrum + melcep at 4096)
+    and streaming, against the oracle."""
+    sr = 96000.0
+    n = 40 * S + W + 123
+    pcm = synth_utterance(2 * n, 77, sr=sr)
+    m, cfg, w = make_pair(pkg, orc, n, W=W, S=S, nb=64, sr=sr, nc=20, dyn=1, l1=2, l2=0)
+    assert m.fft_size() == fft
+    want = orc.run_utterance(cfg, pcm, w, bug_compat=False)
+    m.batch_plan([0], [pcm.size])
+    assert_close(m.batch_run_host(pcm), want, "batch %d" % fft, groups=2)
+    assert_close(m.process_stream(pcm), orc.run_utterance(cfg, pcm, w), "stream %d" % fft, groups=2)
+
+
 def test_c4_per_gpu_share_full_size_properties(pkg, orc):
     """BASELINE configs[3] per GPU: 12 500 utterances x 10 s = 2.0e9 samples (4 GB of PCM, byte offsets past
     2^32) -> 12 475 000 frames.  The batch is 25 copies of one 500-utterance block, so every copy of the
