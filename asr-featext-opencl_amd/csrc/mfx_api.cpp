@@ -111,7 +111,8 @@ struct mfx_handle {
     std::vector<int32_t> chunk_utt;      // utterance of every entry of h_chunks
     DevBuf<Chunk> d_chunks;
     DevBuf<Segment> d_segs;
-    DevBuf<float> d_stats_batch, d_spec_slab;
+    DevBuf<float> d_stats_batch, d_spec_slab, d_host_out;
+    DevBuf<int16_t> d_host_pcm;          // mfx_batch_run_host: device copies of the caller's host buffers
     DevBuf<float> d_static16[2]; // compact [rows][16] statics between front end and delta (double buffered for overlap)
     // optional overlap of the delta/normalisation tail of batch i with the front end of batch i+1
     bool overlap = false;
@@ -366,6 +367,8 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_src.release();
     h->d_blk.release();
     h->d_stats_stream.release();
+    h->d_host_pcm.release();
+    h->d_host_out.release();
     h->d_fchunks.release();
     h->d_blk_chunk_off.release();
     h->d_blk_tile_off.release();
@@ -1444,30 +1447,21 @@ extern "C" int mfx_batch_run_host(mfx_handle *h, const int16_t *pcm, int64_t pcm
 {
     if (!h || !pcm || !out || pcm_samples_total <= 0) return MFX_ERR_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
-    DevBuf<int16_t> d_pcm;
-    DevBuf<float> d_out;
+    // device-side staging of the host buffers, kept by the handle and grown on demand
     const size_t n_in = (size_t)pcm_samples_total * h->channels;
-    HIP_TRY(h, d_pcm.alloc(n_in + 8));
-    hipError_t e = d_out.alloc((size_t)std::max<int64_t>(h->total_rows, 1) * h->width);
-    if (e != hipSuccess) {
-        d_pcm.release();
-        return fail_hip(h, e, "hipMalloc(out)");
+    const size_t n_out = (size_t)std::max<int64_t>(h->total_rows, 1) * h->width;
+    if (h->d_host_pcm.n < n_in + 8) HIP_TRY(h, h->d_host_pcm.alloc(n_in + 8));
+    if (h->d_host_out.n < n_out) HIP_TRY(h, h->d_host_out.alloc(n_out));
+    HIP_TRY(h, hipMemcpyAsync(h->d_host_pcm.p, pcm, n_in * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
+    int rc = mfx_batch_run_device(h, h->d_host_pcm.p, pcm_samples_total, h->d_host_out.p);
+    if (rc != MFX_OK) {
+        (void)hipStreamSynchronize(h->stream);
+        return rc;
     }
-    int rc = MFX_OK;
-    e = hipMemcpyAsync(d_pcm.p, pcm, n_in * sizeof(int16_t), hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) {
-        rc = mfx_batch_run_device(h, d_pcm.p, pcm_samples_total, d_out.p);
-        if (rc == MFX_OK && h->stream2) (void)hipStreamSynchronize(h->stream2); // overlapped tail, if any
-        if (rc == MFX_OK && h->total_rows > 0)
-            e = hipMemcpyAsync(out, d_out.p, (size_t)h->total_rows * h->width * sizeof(float), hipMemcpyDeviceToHost,
-                               h->stream);
-    }
-    hipError_t e2 = hipStreamSynchronize(h->stream);
-    d_pcm.release();
-    d_out.release();
-    if (rc != MFX_OK) return rc;
-    if (e != hipSuccess) return fail_hip(h, e, "batch copy");
-    if (e2 != hipSuccess) return fail_hip(h, e2, "hipStreamSynchronize");
+    if (h->stream2) HIP_TRY(h, hipStreamSynchronize(h->stream2)); // overlapped tail, if any
+    if (h->total_rows > 0)
+        HIP_TRY(h, hipMemcpyAsync(out, h->d_host_out.p, (size_t)h->total_rows * h->width * sizeof(float),
+                                  hipMemcpyDeviceToHost, h->stream));
     return mfx_synchronize(h);
 }
 
