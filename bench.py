@@ -139,8 +139,11 @@ def wl_frames(wl):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # Defaults long enough to measure the steady state: for the first ~10 ms of sustained load an MI355X is still
+    # raising its clocks (a 3 + 20 step run reads 0.58 ms/step where 50 + 500 reads 0.49; profiles/r01/README.md).
+    # 550 steps of the C2 workload are ~0.3 s of GPU time.
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true",

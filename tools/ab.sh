@@ -4,7 +4,7 @@
 mkdir -p gpurun_out/exp
 for v in "" "$@"; do
     name=$(basename "${v:-shipped}" .so)
-    MFX_LIB=$v timeout -k 10 200 python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline \
+    MFX_LIB=$v timeout -k 10 200 python3 bench.py --steps 300 --warmup 50 --no-cpu-baseline \
         > gpurun_out/exp/ab_$name.json 2> gpurun_out/exp/ab_$name.err || { echo "$name FAILED"; tail -3 gpurun_out/exp/ab_$name.err; exit 1; }
     python3 - "$name" gpurun_out/exp/ab_$name.json <<'PY'
 import json, sys
