@@ -1054,8 +1054,23 @@ int plan_fused_delta(mfx_handle *h, const std::vector<int64_t> &T_of)
     std::vector<DeltaTile> tiles;
     std::vector<int32_t> coff((size_t)B + 1), toff((size_t)B + 1);
     size_t max_list = 0;
+    // pieces of equal FRAME count (the tail of the chunk list holds 4-frame chunks): cut[b] = first chunk of block b
+    std::vector<size_t> cut((size_t)B + 1, n);
+    {
+        int64_t total = 0;
+        for (const Chunk &c : h->h_chunks) total += c.n_frames;
+        int64_t acc = 0;
+        size_t c = 0;
+        for (int b = 0; b < B; ++b) {
+            cut[b] = c;
+            const int64_t target = total * (b + 1) / B;
+            while (c < n && acc + h->h_chunks[c].n_frames <= target) acc += h->h_chunks[c++].n_frames;
+            if (b + 1 == B) c = n;
+        }
+        cut[0] = 0;
+    }
     for (int b = 0; b < B; ++b) {
-        const size_t c0 = n * (size_t)b / B, c1 = n * (size_t)(b + 1) / B;
+        const size_t c0 = cut[b], c1 = cut[b + 1];
         coff[b] = (int32_t)fch.size();
         toff[b] = (int32_t)tiles.size();
         if (c1 <= c0) continue;
