@@ -560,7 +560,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int slot = lane >> 4, l = lane & 15;
+    const int slot = lane >> 4, l = lane & 15, odd_slot = slot & 1;
 
     // ---- LDS carve: shared tables, then one 4-slot region per wave
     const int cols = p.cols;
@@ -795,13 +795,14 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
             for (int k = 1; k < 16; ++k) a[k] = cmul(a[k], lds_read_b64(s_tw + k * 16 + l));
 
             MFX_STAMP(2);
-            // ---- 16x16 transpose through the frame slot (XOR swizzle, see above)
+            // ---- 16x16 transpose through the frame slot (XOR swizzle, see above).  Odd slots swap neighbouring
+            // rows: the two slots of a 32-lane access group then write to complementary halves of the banks.
 #pragma unroll
-            for (int k = 0; k < 16; ++k) ((float2 *)(xb + k * 32))[l ^ (k & 14)] = a[k];
+            for (int k = 0; k < 16; ++k) ((float2 *)(xb + (k ^ odd_slot) * 32))[l ^ (k & 14)] = a[k];
             wave_sync();
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float4 v = ((const float4 *)(xb + l * 32))[j ^ (l >> 1)];
+                const float4 v = ((const float4 *)(xb + (l ^ odd_slot) * 32))[j ^ (l >> 1)];
                 a[2 * j] = make_float2(v.x, v.y);
                 a[2 * j + 1] = make_float2(v.z, v.w);
             }
