@@ -23,6 +23,7 @@ from .mfcc import (  # noqa: F401
     MfxError,
     host_dct_matrix,
     host_frame_count,
+    host_mel_item_plan,
     host_mel_table,
     library_path,
     load_library,

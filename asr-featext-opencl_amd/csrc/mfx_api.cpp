@@ -1538,6 +1538,20 @@ extern "C" int mfx_host_mel_table(int32_t num_banks, int32_t fft_size, float sam
     return MFX_OK;
 }
 
+extern "C" int mfx_host_mel_item_plan(int32_t num_banks, const int32_t *beg, int32_t *items, int64_t items_cap,
+                                      int32_t *pieces)
+{
+    if (num_banks <= 0 || !beg) return MFX_ERR_ARG;
+    MelItemPlan plan;
+    build_mel_item_plan(std::vector<int32_t>(beg, beg + num_banks + 2), num_banks, plan);
+    if (items) {
+        if ((int64_t)plan.items.size() > items_cap) return MFX_ERR_ARG;
+        std::memcpy(items, plan.items.data(), sizeof(int32_t) * plan.items.size());
+    }
+    if (pieces) std::memcpy(pieces, plan.pieces.data(), sizeof(int32_t) * plan.pieces.size());
+    return plan.K;
+}
+
 extern "C" int mfx_host_dct_matrix(int32_t num_banks, int32_t ceps_len, int32_t want_c0, float lift_coef,
                                    float *matrix)
 {

@@ -53,7 +53,7 @@ EXPORTED_SYMBOLS = (
     "mfx_create", "mfx_destroy", "mfx_last_error", "mfx_status_string", "mfx_abi_version",
     "mfx_set_window", "mfx_set_input", "mfx_flush", "mfx_set_alpha", "mfx_apply",
     "mfx_get_output_data_width", "mfx_get_output_data", "mfx_get_input_buffer_size",
-    "mfx_apply_alphas", "mfx_get_output_data_alpha",
+    "mfx_apply_alphas", "mfx_get_output_data_alpha", "mfx_host_mel_item_plan",
     "mfx_estimated_window_count", "mfx_max_frames_out", "mfx_fft_size",
     "mfx_batch_frames", "mfx_batch_plan", "mfx_batch_run_device", "mfx_batch_run_host", "mfx_batch_overlap",
     "mfx_set_stream", "mfx_synchronize", "mfx_profile_enable", "mfx_profile_read",
@@ -122,6 +122,7 @@ def load_library():
     L.mfx_host_mel_table.argtypes = [i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, fp, C.POINTER(i32)]
     L.mfx_host_dct_matrix.argtypes = [i32, i32, i32, C.c_float, fp]
     L.mfx_host_frame_count.argtypes, L.mfx_host_frame_count.restype = [i64, i32, i32], i64
+    L.mfx_host_mel_item_plan.argtypes = [i32, C.POINTER(i32), C.POINTER(i32), i64, C.POINTER(i32)]
     _lib = L
     return L
 
@@ -136,6 +137,23 @@ def host_mel_table(num_banks, fft_size, sample_rate, low_freq, high_freq, alpha=
     if rc != 0:
         raise MfxError(rc, "mfx_host_mel_table failed")
     return w, beg
+
+
+def host_mel_item_plan(beg):
+    """Work plan of the wave-per-frame mel stage for filter edges beg[nb + 2]: (items [K][64][4], pieces [nb])."""
+    L = load_library()
+    beg = np.ascontiguousarray(beg, dtype=np.int32)
+    nb = beg.size - 2
+    ip = C.POINTER(C.c_int32)
+    K = L.mfx_host_mel_item_plan(nb, beg.ctypes.data_as(ip), None, 0, None)
+    if K < 0:
+        raise MfxError(K, "mfx_host_mel_item_plan failed")
+    items = np.zeros((K, 64, 4), dtype=np.int32)
+    pieces = np.zeros(nb, dtype=np.int32)
+    rc = L.mfx_host_mel_item_plan(nb, beg.ctypes.data_as(ip), items.ctypes.data_as(ip), items.size, pieces.ctypes.data_as(ip))
+    if rc != K:
+        raise MfxError(rc, "mfx_host_mel_item_plan failed")
+    return items, pieces
 
 
 def host_dct_matrix(num_banks, ceps_len, want_c0, lift_coef):

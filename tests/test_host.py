@@ -89,6 +89,40 @@ def test_dct_matrix_equals_oracle(pkg, orc, nb, nc, c0, lift):
         assert np.all(m[:, nc] == np.float32(np.sqrt(2.0 / nb)))  # c0 is the LAST column
 
 
+@pytest.mark.parametrize("nb,W2,sr,alpha", [(40, 512, 16000.0, 1.0), (80, 1024, 16000.0, 1.0), (128, 2048, 44100.0, 1.0),
+                                             (26, 512, 16000.0, 0.88), (3, 64, 8000.0, 1.0), (128, 4096, 96000.0, 1.12)])
+def test_mel_item_plan_covers_every_bin_once(pkg, nb, W2, sr, alpha):
+    """The work plan of the wave-per-frame mel stage (pieces of every filter's bin range dealt to 64 lanes): every
+    bin of every filter in exactly one piece, pieces of a filter consecutive and ascending, piece counts right,
+    and the lanes' loads even (no lane walks more than the longest single piece beyond the average)."""
+    _, beg = pkg.host_mel_table(nb, W2, sr, 64.0, sr / 2, alpha)
+    items, pieces = pkg.host_mel_item_plan(beg)
+    K = items.shape[0]
+    seen = {}
+    loads = np.zeros(64, dtype=np.int64)
+    for k in range(K):
+        for lane in range(64):
+            slot, b0, b1, _ = items[k, lane]
+            if slot < 0:
+                continue
+            m, piece = divmod(int(slot), 4)
+            assert 0 <= m < nb and piece < pieces[m] and b0 <= b1
+            assert (m, piece) not in seen
+            seen[(m, piece)] = (int(b0), int(b1))
+            loads[lane] += b1 - b0
+    for m in range(nb):
+        assert 1 <= pieces[m] <= 4
+        pos = int(beg[m])
+        for piece in range(pieces[m]):
+            b0, b1 = seen[(m, piece)]
+            assert b0 == min(pos, int(beg[m + 2]))
+            pos = max(pos, b1)
+        assert pos == int(beg[m + 2]) or beg[m + 2] <= beg[m]
+    assert len(seen) == int(pieces.sum())
+    longest = max((b1 - b0 for b0, b1 in seen.values()), default=0)
+    assert loads.max() <= loads.sum() / 64 + longest + 4
+
+
 def test_frame_count_integer_vs_float32(pkg, orc):
     L = orc.lib()
     rng = np.random.default_rng(5)
