@@ -643,7 +643,7 @@ extern "C" int mfx_profile_read(mfx_handle *h, int32_t *launches, double *kernel
 extern "C" const char *mfx_dominant_kernel_name(const mfx_handle *h)
 {
     if (!h) return "";
-    return h->fast512 ? "k_front512" : "k_front_generic";
+    return h->fast512 ? "k_front512" : h->W2 >= 1024 ? "k_front_reg" : "k_front_wave"; // names as rocprofv3 prints them
 }
 
 // ------------------------------------------------------------------------------------------------

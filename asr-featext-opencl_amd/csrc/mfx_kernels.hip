@@ -1300,9 +1300,14 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
                         x0 = (float)(int)(short)(d & 0xffffu);
                         x1 = (float)((int)d >> 16);
                     } else if (ch_n == 2) {
-                        const int64_t s = s0 + 2 * n;
-                        x0 = (float)(((int)p.pcm[2 * s] + (int)p.pcm[2 * s + 1]) >> 1); // stereo -> mono (L + R) >> 1
-                        if (2 * n + 1 < W) x1 = (float)(((int)p.pcm[2 * s + 2] + (int)p.pcm[2 * s + 3]) >> 1);
+                        // interleaved stereo: sample s is one aligned 32-bit word (L | R << 16); mono = (L + R) >> 1
+                        const uint32_t *w32 = (const uint32_t *)p.pcm + (s0 + 2 * n);
+                        const uint32_t d0 = w32[0];
+                        x0 = (float)(((int)(short)(d0 & 0xffffu) + ((int)d0 >> 16)) >> 1);
+                        if (2 * n + 1 < W) {
+                            const uint32_t d1 = w32[1];
+                            x1 = (float)(((int)(short)(d1 & 0xffffu) + ((int)d1 >> 16)) >> 1);
+                        }
                     } else {
                         const int64_t s = s0 + 2 * n;
                         x0 = (float)(int)p.pcm[s];

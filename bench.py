@@ -36,8 +36,9 @@ WORKLOADS = {
               desc="tiny test workload: 8 synthetic 16 kHz utterances x 1 s (launch-path tests only)"),
     "C3": dict(n_utt=1, utt_samples=57600000, sr=16000.0, W=400, S=160, fft=1024, nb=80, nc=13, dyn=0,
                desc="one 1-hour 16 kHz stream, 1024-pt FFT, 80 mel, 13 MFCC"),
-    "C5": dict(n_utt=200, utt_samples=441000, sr=44100.0, W=1102, S=441, fft=0, nb=128, nc=40, dyn=2,
-               desc="200 synthetic 44.1 kHz utterances x 10 s, 2048-pt FFT, 128 mel, 40 MFCC + d + dd (mono)"),
+    "C5": dict(n_utt=200, utt_samples=441000, sr=44100.0, W=1102, S=441, fft=0, nb=128, nc=40, dyn=2, channels=2,
+               desc="200 synthetic 44.1 kHz STEREO utterances x 10 s (downmix (L+R)>>1 in the kernel), 2048-pt FFT, "
+                    "128 mel, 40 MFCC + d + dd"),
 }
 
 
@@ -181,9 +182,12 @@ def main():
     window = pkg.reference_window(W)
 
     # ---- synthetic input resident in HBM (per rank: its own shard of utterances)
+    channels = wl.get("channels", 1)
     pcm = synth_pcm_torch(torch, wl["n_utt"], wl["utt_samples"], wl["sr"], seed=rank, device=device)
+    if channels == 2:   # interleaved L/R: the right channel is the left one of the neighbouring utterance
+        pcm = torch.stack((pcm, torch.roll(pcm, 1, dims=0)), dim=2).contiguous()
     m = pkg.MfccHip(wl["utt_samples"] + 1000, W, S, wl["nb"], wl["sr"], 64.0, wl["sr"] / 2, wl["nc"], False, 22.0,
-                    pkg.NORM_NONE, wl["dyn"], 3, 3, True, device=dev_index, fft_size=wl["fft"])
+                    pkg.NORM_NONE, wl["dyn"], 3, 3, True, device=dev_index, fft_size=wl["fft"], channels=channels)
     m.set_window(window)
     offsets = np.arange(wl["n_utt"], dtype=np.int64) * wl["utt_samples"]
     lengths = np.full(wl["n_utt"], wl["utt_samples"], dtype=np.int64)
@@ -192,7 +196,7 @@ def main():
     rows, total_rows = m.batch_plan(offsets, lengths)
     width = m.get_output_data_width()
     out = torch.empty((total_rows, width), dtype=torch.float32, device=device)
-    n_samples = pcm.numel()
+    n_samples = pcm.numel() // channels     # per channel
     torch.cuda.synchronize()
 
     def step():
@@ -227,7 +231,7 @@ def main():
     value = frames_all / (elapsed / args.steps)
 
     # ---- roofline of the dominant kernel (HIP events on the handle's stream around that kernel)
-    bytes_in = 2 * S
+    bytes_in = 2 * S * channels
     cols = wl["nc"] if wl["nc"] > 0 else wl["nb"]
     kname = m.dominant_kernel_name()
     # the front-end kernel reads each PCM sample once and writes the static coefficients once;
@@ -273,6 +277,8 @@ def main():
         orc = G.load_oracle()
         n_host = min(wl["n_utt"], 512)
         pcm_host = pcm[:n_host].cpu().numpy()
+        if channels == 2:   # the same downmix the kernel applies, done before the timed CPU passes
+            pcm_host = ((pcm_host[..., 0].astype(np.int32) + pcm_host[..., 1].astype(np.int32)) >> 1).astype(np.int16)
         result["cpu_baseline"] = cpu_baseline(orc, wl, pcm_host, window)
         result["cpu_baseline"]["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
     m.close()

@@ -30,9 +30,9 @@ json.dump(res, open(out + "/pmc_summary.json", "w"), indent=1, sort_keys=True)
 # FETCH_SIZE reports half of the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM;
 # confirmed for this kernel's 4-byte-per-lane loads by tools/ubench/fetch_calib.hip: 1 GiB read ->
 # 524 299 KiB), WRITE_SIZE is exact at 32-byte sector granularity (same calibration).
-k = res.get("k_front512") or res.get("k_front_generic") or {}
+k = res.get("k_front512") or {}
 if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
-    traffic = {"kernel": "k_front512" if "k_front512" in res else "k_front_generic", "workload": "C2",
+    traffic = {"kernel": "k_front512", "workload": "C2",
                "fetch_size_kib_raw": k["FETCH_SIZE"], "write_size_kib": k["WRITE_SIZE"],
                "hbm_read_bytes_per_launch": 2 * 1024 * k["FETCH_SIZE"], "hbm_write_bytes_per_launch": 1024 * k["WRITE_SIZE"],
                "hbm_bytes_per_launch": 2 * 1024 * k["FETCH_SIZE"] + 1024 * k["WRITE_SIZE"],
