@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <future>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -152,10 +153,9 @@ void write_rows(FILE *out, const float *rows, int n, int width, int first_frame,
     }
 }
 
-void process_file(MfccHip &param, const Options &o, const std::string &in, const std::string &out_name,
+void process_file(MfccHip &param, const Options &o, const Wav &w, const std::string &in, const std::string &out_name,
                   float sample_rate)
 {
-    Wav w = read_wav(in);
     if ((float)w.sample_rate != sample_rate)
         throw std::runtime_error("File \"" + in + "\" has incorrect sample rate");
     // mono: first channel (the reference reads one short per frame into a mono-sized buffer)
@@ -239,15 +239,30 @@ void worker(const Options &o, int device, float sr, const std::vector<std::strin
         for (long i = 0; i < W; ++i) // ASR_OCL.cpp:149-151
             window[i] = (float)(0.56f - 0.46f * std::cos((2.0f * M_PI * i) / W)) / 32768.f;
         param.set_window(window.data());
-        for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (2 * i + 1 >= files.size()) break;
+        // The worker's next file is claimed and read (its own thread) while the current one is on the GPU.
+        struct Pending {
+            size_t i;
+            std::future<Wav> wav;
+        };
+        auto claim = [&](Pending &p) -> bool {
+            p.i = next.fetch_add(1);
+            if (2 * p.i + 1 >= files.size()) return false;
+            p.wav = std::async(std::launch::async, read_wav, files[2 * p.i]);
+            return true;
+        };
+        Pending cur, nxt;
+        bool have = claim(cur);
+        while (have) {
+            const bool have_next = claim(nxt);
             try {
-                process_file(param, o, files[2 * i], files[2 * i + 1], sr);
+                const Wav w = cur.wav.get();
+                process_file(param, o, w, files[2 * cur.i], files[2 * cur.i + 1], sr);
             } catch (const std::exception &e) { // a bad file does not stop the queue
                 std::fprintf(stderr, "Exception caught %s\n", e.what());
                 ++failures;
             }
+            cur = std::move(nxt);
+            have = have_next;
         }
     } catch (const std::exception &e) {
         std::fprintf(stderr, "Exception caught %s\n", e.what());
