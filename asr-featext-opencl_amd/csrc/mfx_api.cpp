@@ -70,7 +70,8 @@ struct mfx_handle {
     // tables in HBM
     DevBuf<float> d_window, d_winpair, d_twid_pass, d_twid_half, d_twid_split, d_twid_reg, d_mel_w, d_dct;
     DevBuf<int32_t> d_mel_beg, d_mel_items, d_mel_pieces;
-    int mel_K = 0;
+    DevBuf<float> d_mel_item_w, d_sweep_item_w;
+    int mel_K = 0, mel_wlen = 0, sweep_wlen = 0;
     // 512-point kernel: per-lane mel plan + transposed DCT matrix
     DevBuf<float> d_mel_lane_w, d_dct_t, d_dct_lane_w;
     int dct_lane_stride = 0;
@@ -186,10 +187,12 @@ int refresh_mel(mfx_handle *h)
     HIP_TRY(h, upload(h->d_mel_beg, t.beg));
     {
         MelItemPlan ip;
-        build_mel_item_plan(t.beg, h->nb, ip);
+        build_mel_item_plan(t, h->nb, h->W2, ip);
         HIP_TRY(h, upload(h->d_mel_items, ip.items));
         HIP_TRY(h, upload(h->d_mel_pieces, ip.pieces));
+        HIP_TRY(h, upload(h->d_mel_item_w, ip.w));
         h->mel_K = ip.K;
+        h->mel_wlen = (int)ip.w.size();
     }
     h->fused_ok = false;
     if (h->fast512 && build_mel_lane_plan(t, h->nb, h->W2, /*max_read_bin=*/511 - 32, h->plan)) {
@@ -227,7 +230,9 @@ void fill_front(const mfx_handle *h, FrontParams &p)
     p.mel_beg = h->d_mel_beg.p;
     p.mel_items = h->d_mel_items.p;
     p.mel_pieces = h->d_mel_pieces.p;
+    p.mel_item_w = h->d_mel_item_w.p;
     p.mel_K = h->mel_K;
+    p.mel_wlen = h->mel_wlen;
     p.dct = h->ceps > 0 ? h->d_dct.p : nullptr;
     p.num_banks = h->nb;
     p.dct_len = h->dl;
@@ -353,6 +358,8 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_dct.release();
     h->d_mel_beg.release();
     h->d_mel_items.release();
+    h->d_mel_item_w.release();
+    h->d_sweep_item_w.release();
     h->d_mel_pieces.release();
     h->d_sweep_items.release();
     h->d_sweep_pieces.release();
@@ -813,6 +820,7 @@ int prepare_sweep(mfx_handle *h, const float *alphas, int n)
     std::vector<int32_t> b(bstride * n);
     std::vector<MelItemPlan> plans((size_t)n);
     int K = 1;
+    size_t wlen = 8;
     for (int a = 0; a < n; ++a) {
         MelTable t;
         build_mel_table(h->nb, h->W2, h->cfg.sample_rate, h->cfg.low_freq, h->cfg.high_freq, alphas[a], t);
@@ -820,23 +828,28 @@ int prepare_sweep(mfx_handle *h, const float *alphas, int n)
             if (v < 0 || v > h->W2 / 2) return fail(h, MFX_ERR_CONFIG, "mel filter edge outside [0, fft_size/2]");
         std::copy(t.weights.begin(), t.weights.end(), w.begin() + wstride * a);
         std::copy(t.beg.begin(), t.beg.end(), b.begin() + bstride * a);
-        build_mel_item_plan(t.beg, h->nb, plans[a]);
+        build_mel_item_plan(t, h->nb, h->W2, plans[a]);
         K = std::max(K, plans[a].K);
+        wlen = std::max(wlen, plans[a].w.size());
     }
     // one item table per alpha, all padded to the longest plan (idle entries have slot -1)
     std::vector<int32_t> items((size_t)n * K * 256, 0), pieces((size_t)n * h->nb);
+    std::vector<float> item_w((size_t)n * wlen, 0.f);
     for (int a = 0; a < n; ++a) {
         int32_t *dst = &items[(size_t)a * K * 256];
         for (int i = 0; i < K * 64; ++i) dst[4 * i] = -1;
         std::copy(plans[a].items.begin(), plans[a].items.end(), dst);
         std::copy(plans[a].pieces.begin(), plans[a].pieces.end(), pieces.begin() + (size_t)a * h->nb);
+        std::copy(plans[a].w.begin(), plans[a].w.end(), item_w.begin() + (size_t)a * wlen);
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(h->d_sweep_w.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_sweep_beg.p, b.data(), b.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(h, upload(h->d_sweep_items, items));
     HIP_TRY(h, upload(h->d_sweep_pieces, pieces));
+    HIP_TRY(h, upload(h->d_sweep_item_w, item_w));
     h->sweep_K = K;
+    h->sweep_wlen = (int)wlen;
     h->sweep_alphas.assign(alphas, alphas + n);
     return MFX_OK;
 }
@@ -890,9 +903,12 @@ int apply_impl(mfx_handle *h, const float *alphas, int n_alpha)
     mp.mel_beg = sweep ? h->d_sweep_beg.p : h->d_mel_beg.p;
     mp.mel_items = sweep ? h->d_sweep_items.p : h->d_mel_items.p;
     mp.mel_pieces = sweep ? h->d_sweep_pieces.p : h->d_mel_pieces.p;
+    mp.mel_item_w = sweep ? h->d_sweep_item_w.p : h->d_mel_item_w.p;
     mp.mel_K = sweep ? h->sweep_K : h->mel_K;
+    mp.mel_wlen = sweep ? h->sweep_wlen : h->mel_wlen;
     mp.mel_items_stride = mp.mel_K * 256;
     mp.mel_pieces_stride = h->nb;
+    mp.mel_item_w_stride = mp.mel_wlen;
     mp.dct = h->ceps > 0 ? h->d_dct.p : nullptr;
     mp.num_banks = h->nb;
     mp.dct_len = h->dl;
@@ -1381,7 +1397,9 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
             mp.mel_beg = h->d_mel_beg.p;
             mp.mel_items = h->d_mel_items.p;
             mp.mel_pieces = h->d_mel_pieces.p;
+            mp.mel_item_w = h->d_mel_item_w.p;
             mp.mel_K = h->mel_K;
+            mp.mel_wlen = h->mel_wlen;
             mp.dct = h->ceps > 0 ? h->d_dct.p : nullptr;
             mp.num_banks = h->nb;
             mp.dct_len = h->dl;
@@ -1538,15 +1556,23 @@ extern "C" int mfx_host_mel_table(int32_t num_banks, int32_t fft_size, float sam
     return MFX_OK;
 }
 
-extern "C" int mfx_host_mel_item_plan(int32_t num_banks, const int32_t *beg, int32_t *items, int64_t items_cap,
-                                      int32_t *pieces)
+extern "C" int mfx_host_mel_item_plan(int32_t num_banks, int32_t fft_size, const float *weights, const int32_t *beg,
+                                      int32_t *items, int64_t items_cap, int32_t *pieces, float *w, int64_t w_cap,
+                                      int64_t *w_len)
 {
-    if (num_banks <= 0 || !beg) return MFX_ERR_ARG;
+    if (num_banks <= 0 || fft_size <= 0 || !weights || !beg) return MFX_ERR_ARG;
+    MelTable t;
+    t.weights.assign(weights, weights + (size_t)2 * fft_size);
+    t.beg.assign(beg, beg + num_banks + 2);
+    for (int v : t.beg)
+        if (v < 0 || v > fft_size / 2) return MFX_ERR_ARG;
     MelItemPlan plan;
-    build_mel_item_plan(std::vector<int32_t>(beg, beg + num_banks + 2), num_banks, plan);
+    build_mel_item_plan(t, num_banks, fft_size, plan);
+    if (w_len) *w_len = (int64_t)plan.w.size();
     if (items) {
-        if ((int64_t)plan.items.size() > items_cap) return MFX_ERR_ARG;
+        if ((int64_t)plan.items.size() > items_cap || (w && (int64_t)plan.w.size() > w_cap)) return MFX_ERR_ARG;
         std::memcpy(items, plan.items.data(), sizeof(int32_t) * plan.items.size());
+        if (w) std::memcpy(w, plan.w.data(), sizeof(float) * plan.w.size());
     }
     if (pieces) std::memcpy(pieces, plan.pieces.data(), sizeof(int32_t) * plan.pieces.size());
     return plan.K;

@@ -74,7 +74,8 @@ struct FrontParams {
     // wave-per-frame mel stage (mel_log_dct): filter pieces dealt to the 64 lanes (MelItemPlan)
     const int32_t *mel_items;     // [mel_K][64][4]
     const int32_t *mel_pieces;    // [nb]
-    int32_t mel_K;
+    const float *mel_item_w;      // [mel_wlen] per-piece weights (multiples of 8 floats)
+    int32_t mel_K, mel_wlen;
     // 512 fast path: mel filters dealt to the 16 lanes of a frame in `mel_rounds` rounds, round r
     // padded to mel_L[r] bins (multiple of 4); lane j's weights for all rounds are one row of mel_lane_w
     const float *mel_lane_w;      // [16][mel_row_stride]
@@ -117,8 +118,9 @@ struct MelcepParams {
     int32_t num_banks, dct_len, cols;
     const int32_t *mel_items;     // [mel_K][64][4] filter pieces dealt to the lanes (MelItemPlan)
     const int32_t *mel_pieces;    // [nb]
-    int32_t mel_K;
-    int32_t mel_items_stride, mel_pieces_stride; // per table of a sweep, in int32 elements
+    const float *mel_item_w;      // [mel_wlen] per-piece weights
+    int32_t mel_K, mel_wlen;
+    int32_t mel_items_stride, mel_pieces_stride, mel_item_w_stride; // per table of a sweep, in elements
     // VTLN sweep: n_tables (>= 1) warped filterbanks over the same spectrum in one launch; table a is
     // mel_w + a * mel_w_stride / mel_beg + a * mel_beg_stride and writes feat + a * feat_table_stride
     int32_t n_tables;

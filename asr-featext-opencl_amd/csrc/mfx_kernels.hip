@@ -94,28 +94,30 @@ __host__ __device__ inline int mel_scratch_floats(int nb, int cols) { return ((n
 // block-shared LDS words of the mel work plan: items [K][64][4] + pieces [nb]
 __host__ __device__ inline int mel_plan_words(int nb, int K) { return K * 256 + ((nb + 3) & ~3); }
 
-// Walk the bins [b0, b1) of one filter piece in ascending order, 8 bins per trip: the 16 LDS reads of a trip
-// are issued together; bins past b1 are read (the buffers extend at least 8 words past any bin) and
-// discarded by a select, so there is no scalar remainder loop with its dependent read latencies.
-__device__ __forceinline__ float mel_filter_sum(const float *w, const float *mag, int b0, int b1)
+// One filter piece: `trips` x 8 bins from the 4-aligned bin a0, weights in the piece's own padded array (exact
+// zeros outside the filter's range), summed in ascending bin order; everything comes as 16-byte LDS reads.
+// The magnitude buffer must hold FINITE values up to 10 words past the last bin (0 * x).
+__device__ __forceinline__ float mel_piece_sum(const float *w, const float *mag_a0, int trips)
 {
     float acc = 0.f;
-    for (int k = b0; k < b1; k += 8) {
-        float wv[8], mv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            wv[u] = w[k + u];
-            mv[u] = mag[k + u];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += (k + u < b1) ? wv[u] * mv[u] : 0.f;
+    for (int t = 0; t < trips; ++t) {
+        const float4 w0 = *(const float4 *)(w + 8 * t), w1 = *(const float4 *)(w + 8 * t + 4);
+        const float4 m0 = *(const float4 *)(mag_a0 + 8 * t), m1 = *(const float4 *)(mag_a0 + 8 * t + 4);
+        acc += w0.x * m0.x;
+        acc += w0.y * m0.y;
+        acc += w0.z * m0.z;
+        acc += w0.w * m0.w;
+        acc += w1.x * m1.x;
+        acc += w1.y * m1.y;
+        acc += w1.z * m1.z;
+        acc += w1.w * m1.w;
     }
     return acc;
 }
 
 template <int G>
-__device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int g, const float *s_w0,
-                                            const float *s_w1, const int4 *s_items, const int *s_pieces, int K,
+__device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int g, const float *s_mw,
+                                            const int4 *s_items, const int *s_pieces, int K,
                                             const float *s_dct, int nb, int dct_len, int cols, float *out_row)
 {
     static_assert(G == 64, "one wave per frame");
@@ -127,7 +129,7 @@ __device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int
     float *mpart = melbuf + ((nb + 3) & ~3) + 8 * ((cols + 3) & ~3); // [nb][4]
     for (int k = 0; k < K; ++k) {
         const int4 it = s_items[k * 64 + g];
-        if (it.x >= 0) mpart[it.x] = mel_filter_sum(((it.x >> 2) & 1) ? s_w1 : s_w0, mag, it.y, it.z);
+        if (it.x >= 0) mpart[it.x] = mel_piece_sum(s_mw + it.w, mag + it.y, it.z);
     }
     wave_sync();
     for (int m = g; m < nb; m += G) {
@@ -1016,13 +1018,11 @@ __global__ void __launch_bounds__(256) k_front_wave(FrontParams p)
         else
             __syncthreads();
     };
-    const int W2 = p.fft_size, M = W2 >> 1, nbins = M + 1;
-    const int bins_pad = (nbins + 3) & ~3;
+    const int W2 = p.fft_size, M = W2 >> 1;
     const int nb = p.num_banks, dl = p.dct_len;
     // shared tables (FUSED only), then per wave: two complex buffers of M points + mel scratch
-    float *s_w0 = smem;
-    float *s_w1 = s_w0 + (FUSED ? bins_pad : 0);
-    int4 *s_items = (int4 *)(s_w1 + (FUSED ? bins_pad : 0)); // mel work plan: items [K][64], then pieces [nb]
+    float *s_mw = smem;                                       // per-piece mel weights
+    int4 *s_items = (int4 *)(s_mw + (FUSED ? p.mel_wlen : 0)); // mel work plan: items [K][64], then pieces [nb]
     int *s_pieces = (int *)s_items + p.mel_K * 256;
     float *s_dct = (float *)((int *)s_items + (FUSED ? mel_plan_words(nb, p.mel_K) : 0));
     const int dl4 = (dl + 3) & ~3;               // DCT rows padded to whole 16-byte words in LDS
@@ -1034,10 +1034,7 @@ __global__ void __launch_bounds__(256) k_front_wave(FrontParams p)
     float2 *bufB = bufA + M;
     float *s_mel = s_wave + 4 * M;
     if (FUSED) {
-        for (int i = tid; i < nbins; i += 256) {
-            s_w0[i] = p.mel_w[i];
-            s_w1[i] = p.mel_w[W2 + i];
-        }
+        for (int i = tid; i < p.mel_wlen; i += 256) s_mw[i] = p.mel_item_w[i];
         for (int i = tid; i < p.mel_K * 256; i += 256) ((int *)s_items)[i] = p.mel_items[i];
         for (int i = tid; i < nb; i += 256) s_pieces[i] = p.mel_pieces[i];
         for (int i = tid; i < dct_floats; i += 256) {
@@ -1136,7 +1133,7 @@ __global__ void __launch_bounds__(256) k_front_wave(FrontParams p)
             }
             group_sync();
             if (FUSED) {
-                mel_log_dct<G>(mag, s_mel, lane, s_w0, s_w1, s_items, s_pieces, p.mel_K, p.dct ? s_dct : nullptr, nb, dl, p.cols,
+                mel_log_dct<G>(mag, s_mel, lane, s_mw, s_items, s_pieces, p.mel_K, p.dct ? s_dct : nullptr, nb, dl, p.cols,
                                 p.feat + (ch.out_row + f) * (int64_t)p.feat_pitch);
                 group_sync();
             }
@@ -1236,7 +1233,7 @@ __device__ __forceinline__ void stockham_pass(float2 *buf, const float2 *s_tw, i
 template <int LOG2M, bool FUSED, bool PAIR>
 __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 512 : 1024) k_front_reg(FrontParams p)
 {
-    constexpr int M = 1 << LOG2M, W2 = 2 * M, NV = M / 64;
+    constexpr int M = 1 << LOG2M, NV = M / 64;
     constexpr int R1 = (LOG2M == 9) ? 8 : 16, R2 = R1, R3 = M / (R1 * R2);
     constexpr int LP = (LOG2M == 9) ? 3 : 4, MP = M + (M >> LP); // padded buffer (pad_idx)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1247,10 +1244,8 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
     float2 *s_tw = (float2 *)smem;                 // pass 1 [R1-1][M/R1], then pass 2 [R2-1][M/(R1 R2)]; M slots reserved
     float2 *s_cs = s_tw + M;                       // [M/2 + 1]  -i W_{2M}^k (one per bin pair), padded to even
     float2 *s_win = s_cs + (M / 2 + 2);            // [M]   (w[2n], w[2n+1]) * 0.5 / W2
-    float *s_w0 = (float *)(s_win + M);
-    constexpr int bins_pad = (M + 1 + 3) & ~3;
-    float *s_w1 = s_w0 + (FUSED ? bins_pad : 0);
-    int4 *s_items = (int4 *)(s_w1 + (FUSED ? bins_pad : 0)); // mel work plan: items [K][64], then pieces [nb]
+    float *s_mw = (float *)(s_win + M);                        // per-piece mel weights
+    int4 *s_items = (int4 *)(s_mw + (FUSED ? p.mel_wlen : 0)); // mel work plan: items [K][64], then pieces [nb]
     int *s_pieces = (int *)s_items + p.mel_K * 256;
     float *s_dct = (float *)((int *)s_items + (FUSED ? mel_plan_words(nb, p.mel_K) : 0));
     const int dl4 = (dl + 3) & ~3;               // DCT rows padded to whole 16-byte words in LDS
@@ -1270,10 +1265,7 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
     }
     for (int i = tid; i <= M / 2; i += blockDim.x) s_cs[i] = ((const float2 *)p.twid_split)[i];
     if (FUSED) {
-        for (int i = tid; i < M + 1; i += blockDim.x) {
-            s_w0[i] = p.mel_w[i];
-            s_w1[i] = p.mel_w[W2 + i];
-        }
+        for (int i = tid; i < p.mel_wlen; i += blockDim.x) s_mw[i] = p.mel_item_w[i];
         for (int i = tid; i < p.mel_K * 256; i += blockDim.x) ((int *)s_items)[i] = p.mel_items[i];
         for (int i = tid; i < nb; i += blockDim.x) s_pieces[i] = p.mel_pieces[i];
         for (int i = tid; i < dct_floats; i += blockDim.x) {
@@ -1359,7 +1351,7 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
                 }
                 if (lane == 0) mag[M / 2] = mag_lo[NP];
                 wave_sync();
-                mel_log_dct<64>(mag, s_mel, lane, s_w0, s_w1, s_items, s_pieces, p.mel_K, p.dct ? s_dct : nullptr, nb, dl, p.cols,
+                mel_log_dct<64>(mag, s_mel, lane, s_mw, s_items, s_pieces, p.mel_K, p.dct ? s_dct : nullptr, nb, dl, p.cols,
                                 p.feat + (ch.out_row + f) * (int64_t)p.feat_pitch);
                 wave_sync();
             } else {
@@ -1384,11 +1376,10 @@ __global__ void __launch_bounds__(256) k_melcep(MelcepParams p)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int W2 = p.fft_size, nbins = (W2 >> 1) + 1;
-    const int bins_pad = (nbins + 3) & ~3;
+    const int bins_pad = (nbins + 12 + 3) & ~3;  // + slack: the mel pieces read up to 10 words past the last bin
     const int nb = p.num_banks, dl = p.dct_len;
-    float *s_w0 = smem;
-    float *s_w1 = s_w0 + bins_pad;
-    int4 *s_items = (int4 *)(s_w1 + bins_pad); // mel work plan: items [K][64], then pieces [nb]
+    float *s_mw = smem;                                      // per-piece mel weights
+    int4 *s_items = (int4 *)(s_mw + p.mel_wlen);             // mel work plan: items [K][64], then pieces [nb]
     int *s_pieces = (int *)s_items + p.mel_K * 256;
     float *s_dct = (float *)((int *)s_items + mel_plan_words(nb, p.mel_K));
     const int dl4 = (dl + 3) & ~3;               // DCT rows padded to whole 16-byte words in LDS
@@ -1399,27 +1390,25 @@ __global__ void __launch_bounds__(256) k_melcep(MelcepParams p)
     float *s_mel = s_mag + bins_pad;
 
     // blockIdx.y = filterbank of a VTLN sweep (one table per alpha over the same spectrum)
-    const float *mel_w = p.mel_w + (int64_t)blockIdx.y * p.mel_w_stride;
+    const float *mel_item_w = p.mel_item_w + (int64_t)blockIdx.y * p.mel_item_w_stride;
     const int32_t *mel_items = p.mel_items + (int64_t)blockIdx.y * p.mel_items_stride;
     const int32_t *mel_pieces = p.mel_pieces + (int64_t)blockIdx.y * p.mel_pieces_stride;
     float *feat = p.feat + (int64_t)blockIdx.y * p.feat_table_stride;
-    for (int i = tid; i < nbins; i += 256) {
-        s_w0[i] = mel_w[i];
-        s_w1[i] = mel_w[W2 + i];
-    }
+    for (int i = tid; i < p.mel_wlen; i += 256) s_mw[i] = mel_item_w[i];
     for (int i = tid; i < p.mel_K * 256; i += 256) ((int *)s_items)[i] = mel_items[i];
     for (int i = tid; i < nb; i += 256) s_pieces[i] = mel_pieces[i];
     for (int i = tid; i < dct_floats; i += 256) {
         const int m = i / dl4, c = i - m * dl4;
         s_dct[i] = c < dl ? p.dct[m * dl + c] : 0.f;
     }
+    for (int i = lane; i < bins_pad; i += 64) s_mag[i] = 0.f; // the slack words stay zero (finite) for good
     __syncthreads();
 
     for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < p.n_rows; r += (int64_t)gridDim.x * 4) {
         const float *src = p.spec + r * p.spec_pitch;
         for (int k = lane; k < nbins; k += 64) s_mag[k] = src[k];
         wave_sync();
-        mel_log_dct<64>(s_mag, s_mel, lane, s_w0, s_w1, s_items, s_pieces, p.mel_K, p.dct ? s_dct : nullptr, nb, dl, p.cols,
+        mel_log_dct<64>(s_mag, s_mel, lane, s_mw, s_items, s_pieces, p.mel_K, p.dct ? s_dct : nullptr, nb, dl, p.cols,
                         feat + r * p.feat_pitch);
         wave_sync();
     }
@@ -1743,7 +1732,7 @@ size_t front_reg_lds_floats(const FrontParams &p, bool fused, int n_waves)
     const size_t M = (size_t)p.fft_size >> 1;
     size_t f = 2 * M + 2 * (M / 2 + 2) + 2 * M; // pass twiddles, split twiddles, window pairs
     if (fused) {
-        f += 2 * ((M + 1 + 3) & ~(size_t)3) + mel_plan_words(p.num_banks, p.mel_K);
+        f += (size_t)p.mel_wlen + mel_plan_words(p.num_banks, p.mel_K);
         f += p.dct ? (size_t)p.num_banks * ((p.dct_len + 3) & ~3) : 0;
     }
     const size_t MP = M + (M >> (p.fft_size == 1024 ? 3 : 4)); // padded buffer (pad_idx)
@@ -1788,10 +1777,10 @@ size_t front_wave_lds_bytes(const FrontParams &p, bool fused)
         const int nw = front_reg_waves(p, fused);
         return nw ? front_reg_lds_floats(p, fused, nw) * sizeof(float) : (size_t)1 << 30;
     }
-    const int M = p.fft_size >> 1, nbins = M + 1, bins_pad = (nbins + 3) & ~3;
+    const int M = p.fft_size >> 1;
     size_t f = 0;
     if (fused) {
-        f += 2 * (size_t)bins_pad + mel_plan_words(p.num_banks, p.mel_K);
+        f += (size_t)p.mel_wlen + mel_plan_words(p.num_banks, p.mel_K);
         f += p.dct ? (size_t)p.num_banks * ((p.dct_len + 3) & ~3) : 0;
     }
     f += 4 * ((size_t)4 * M + (fused ? mel_scratch_floats(p.num_banks, p.cols) : 0));
@@ -1828,9 +1817,9 @@ hipError_t launch_front_generic(const FrontParams &p, bool fused, hipStream_t st
 hipError_t launch_melcep(const MelcepParams &p, hipStream_t stream)
 {
     if (p.n_rows <= 0) return hipSuccess;
-    const int nbins = (p.fft_size >> 1) + 1, bins_pad = (nbins + 3) & ~3;
+    const int nbins = (p.fft_size >> 1) + 1, bins_pad = (nbins + 12 + 3) & ~3;
     const int nb = p.num_banks;
-    size_t f = 2 * bins_pad + mel_plan_words(nb, p.mel_K) + (p.dct ? nb * ((p.dct_len + 3) & ~3) : 0) +
+    size_t f = (size_t)p.mel_wlen + mel_plan_words(nb, p.mel_K) + (p.dct ? nb * ((p.dct_len + 3) & ~3) : 0) +
                4 * (bins_pad + mel_scratch_floats(nb, p.cols));
     const size_t lds = f * sizeof(float);
     if (lds > 64 * 1024) {

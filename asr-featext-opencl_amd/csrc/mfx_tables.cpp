@@ -192,8 +192,9 @@ void build_dct_transposed(const std::vector<float> &dct, int num_banks, int dct_
         for (int c = 0; c < dct_len; ++c) out[(size_t)c * stride + m] = dct[(size_t)m * dct_len + c];
 }
 
-void build_mel_item_plan(const std::vector<int32_t> &beg, int num_banks, MelItemPlan &out)
+void build_mel_item_plan(const MelTable &t, int num_banks, int fft_size, MelItemPlan &out)
 {
+    const std::vector<int32_t> &beg = t.beg;
     struct Item {
         int slot, b0, b1;
     };
@@ -229,18 +230,24 @@ void build_mel_item_plan(const std::vector<int32_t> &beg, int num_banks, MelItem
     for (auto &v : lane_items) K = std::max(K, v.size());
     out.K = (int)K;
     out.items.assign(K * 64 * 4, 0);
+    out.w.clear();
     for (size_t k = 0; k < K; ++k)
         for (int l = 0; l < 64; ++l) {
             int32_t *e = &out.items[(k * 64 + l) * 4];
-            if (k < lane_items[l].size()) {
-                const Item &it = items[lane_items[l][k]];
-                e[0] = it.slot;
-                e[1] = it.b0;
-                e[2] = it.b1;
-            } else {
+            if (k >= lane_items[l].size()) {
                 e[0] = -1;
+                continue;
             }
+            const Item &it = items[lane_items[l][k]];
+            const int a0 = it.b0 & ~3, trips = (it.b1 - a0 + 7) / 8;
+            const float *row = t.weights.data() + (size_t)(((it.slot >> 2) & 1) ? fft_size : 0);
+            e[0] = it.slot;
+            e[1] = a0;
+            e[2] = trips;
+            e[3] = (int32_t)out.w.size();
+            for (int j = a0; j < a0 + 8 * trips; ++j) out.w.push_back((j >= it.b0 && j < it.b1) ? row[j] : 0.0f);
         }
+    if (out.w.empty()) out.w.assign(8, 0.0f);
 }
 
 } // namespace mfx

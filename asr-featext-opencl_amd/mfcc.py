@@ -122,7 +122,8 @@ def load_library():
     L.mfx_host_mel_table.argtypes = [i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, fp, C.POINTER(i32)]
     L.mfx_host_dct_matrix.argtypes = [i32, i32, i32, C.c_float, fp]
     L.mfx_host_frame_count.argtypes, L.mfx_host_frame_count.restype = [i64, i32, i32], i64
-    L.mfx_host_mel_item_plan.argtypes = [i32, C.POINTER(i32), C.POINTER(i32), i64, C.POINTER(i32)]
+    L.mfx_host_mel_item_plan.argtypes = [i32, i32, fp, C.POINTER(i32), C.POINTER(i32), i64, C.POINTER(i32), fp, i64,
+                                         C.POINTER(i64)]
     _lib = L
     return L
 
@@ -139,21 +140,27 @@ def host_mel_table(num_banks, fft_size, sample_rate, low_freq, high_freq, alpha=
     return w, beg
 
 
-def host_mel_item_plan(beg):
-    """Work plan of the wave-per-frame mel stage for filter edges beg[nb + 2]: (items [K][64][4], pieces [nb])."""
+def host_mel_item_plan(weights, beg):
+    """Work plan of the wave-per-frame mel stage for a mel table (host_mel_table): items [K][64][4], pieces [nb] and
+    the pieces' zero-padded weights."""
     L = load_library()
+    weights = np.ascontiguousarray(weights, dtype=np.float32)
     beg = np.ascontiguousarray(beg, dtype=np.int32)
-    nb = beg.size - 2
-    ip = C.POINTER(C.c_int32)
-    K = L.mfx_host_mel_item_plan(nb, beg.ctypes.data_as(ip), None, 0, None)
+    nb, fft = beg.size - 2, weights.shape[1]
+    ip, fpt = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    wlen = C.c_int64(0)
+    K = L.mfx_host_mel_item_plan(nb, fft, weights.ctypes.data_as(fpt), beg.ctypes.data_as(ip), None, 0, None, None, 0,
+                                 C.byref(wlen))
     if K < 0:
         raise MfxError(K, "mfx_host_mel_item_plan failed")
     items = np.zeros((K, 64, 4), dtype=np.int32)
     pieces = np.zeros(nb, dtype=np.int32)
-    rc = L.mfx_host_mel_item_plan(nb, beg.ctypes.data_as(ip), items.ctypes.data_as(ip), items.size, pieces.ctypes.data_as(ip))
+    w = np.zeros(wlen.value, dtype=np.float32)
+    rc = L.mfx_host_mel_item_plan(nb, fft, weights.ctypes.data_as(fpt), beg.ctypes.data_as(ip), items.ctypes.data_as(ip),
+                                  items.size, pieces.ctypes.data_as(ip), w.ctypes.data_as(fpt), w.size, C.byref(wlen))
     if rc != K:
         raise MfxError(rc, "mfx_host_mel_item_plan failed")
-    return items, pieces
+    return items, pieces, w
 
 
 def host_dct_matrix(num_banks, ceps_len, want_c0, lift_coef):

@@ -92,35 +92,44 @@ def test_dct_matrix_equals_oracle(pkg, orc, nb, nc, c0, lift):
 @pytest.mark.parametrize("nb,W2,sr,alpha", [(40, 512, 16000.0, 1.0), (80, 1024, 16000.0, 1.0), (128, 2048, 44100.0, 1.0),
                                              (26, 512, 16000.0, 0.88), (3, 64, 8000.0, 1.0), (128, 4096, 96000.0, 1.12)])
 def test_mel_item_plan_covers_every_bin_once(pkg, nb, W2, sr, alpha):
-    """The work plan of the wave-per-frame mel stage (pieces of every filter's bin range dealt to 64 lanes): every
-    bin of every filter in exactly one piece, pieces of a filter consecutive and ascending, piece counts right,
-    and the lanes' loads even (no lane walks more than the longest single piece beyond the average)."""
-    _, beg = pkg.host_mel_table(nb, W2, sr, 64.0, sr / 2, alpha)
-    items, pieces = pkg.host_mel_item_plan(beg)
+    """The work plan of the wave-per-frame mel stage (pieces of every filter's bin range dealt to 64 lanes, each
+    with its own zero-padded weights): over a filter's pieces, taken in order, every bin of the filter carries its
+    table weight exactly once and in ascending order, every other entry is an exact zero; piece counts are right;
+    reads stay within 10 words of the last bin; the lanes' loads are even."""
+    wt, beg = pkg.host_mel_table(nb, W2, sr, 64.0, sr / 2, alpha)
+    items, pieces, w = pkg.host_mel_item_plan(wt, beg)
     K = items.shape[0]
     seen = {}
     loads = np.zeros(64, dtype=np.int64)
     for k in range(K):
         for lane in range(64):
-            slot, b0, b1, _ = items[k, lane]
+            slot, a0, trips, off = (int(v) for v in items[k, lane])
             if slot < 0:
                 continue
-            m, piece = divmod(int(slot), 4)
-            assert 0 <= m < nb and piece < pieces[m] and b0 <= b1
+            m, piece = divmod(slot, 4)
+            assert 0 <= m < nb and piece < pieces[m] and a0 % 4 == 0 and off % 8 == 0 and trips >= 0
+            assert a0 + 8 * trips <= W2 // 2 + 1 + 10
             assert (m, piece) not in seen
-            seen[(m, piece)] = (int(b0), int(b1))
-            loads[lane] += b1 - b0
+            seen[(m, piece)] = (a0, w[off:off + 8 * trips])
+            loads[lane] += 8 * trips
+    assert len(seen) == int(pieces.sum())
     for m in range(nb):
         assert 1 <= pieces[m] <= 4
-        pos = int(beg[m])
+        got = np.zeros(W2 // 2 + 16, dtype=np.float32)
+        last_bin = -1
         for piece in range(pieces[m]):
-            b0, b1 = seen[(m, piece)]
-            assert b0 == min(pos, int(beg[m + 2]))
-            pos = max(pos, b1)
-        assert pos == int(beg[m + 2]) or beg[m + 2] <= beg[m]
-    assert len(seen) == int(pieces.sum())
-    longest = max((b1 - b0 for b0, b1 in seen.values()), default=0)
-    assert loads.max() <= loads.sum() / 64 + longest + 4
+            a0, wp = seen[(m, piece)]
+            nz = np.nonzero(wp)[0]
+            if nz.size:
+                assert a0 + nz[0] > last_bin          # pieces ascend, no bin twice
+                last_bin = a0 + nz[-1]
+            got[a0:a0 + wp.size] += wp
+        want = np.zeros_like(got)
+        b0, b1 = int(beg[m]), int(beg[m + 2])
+        want[b0:b1] = wt[m & 1, b0:b1]
+        assert np.array_equal(got, want)
+    longest = max((wp.size for _, wp in seen.values()), default=0)
+    assert loads.max() <= loads.sum() / 64 + longest + 8
 
 
 def test_frame_count_integer_vs_float32(pkg, orc):
