@@ -123,7 +123,25 @@ def cpu_baseline(orc, wl, pcm_host, window, budget_s=12.0):
     probe_rate, _, _ = run(n_all, cores, 1)        # short probe so that the timed sample fits the budget
     reps = int(max(1, (budget_s * 0.75) * probe_rate / (fpu * n_all)))
     rall, dtall, fall = run(n_all, cores, reps)
+    # FFTW itself is not installed: as an FFTW-class proxy, the FFT stage ALONE through scipy's
+    # pocketfft (float32 real FFT of the workload's length over the same number of host threads)
+    fft_proxy = None
+    try:
+        import scipy.fft
+        W2 = wl["fft"] or (1 << (wl["W"] - 1).bit_length())
+        x = np.random.default_rng(0).standard_normal((1 << 16, W2)).astype(np.float32)
+        scipy.fft.rfft(x[:1024], axis=1, workers=cores)
+        t0 = time.perf_counter()
+        n_pass = 0
+        while time.perf_counter() - t0 < 1.5:
+            scipy.fft.rfft(x, axis=1, workers=cores)
+            n_pass += 1
+        fft_proxy = {"what": "scipy.fft.rfft (pocketfft), float32, %d-point, %d workers: the FFT stage alone" % (W2, cores),
+                     "frames_per_s": n_pass * x.shape[0] / (time.perf_counter() - t0)}
+    except Exception:
+        fft_proxy = None
     return {
+        "fft_stage_proxy": fft_proxy,
         "value": rall, "unit": "frames/s", "cores": cores, "kind": "port",
         "sample": "%d utterances of the workload x %d passes = %d frames on all %d host threads (OpenMP, one "
                   "extractor per thread, setup untimed), %.1f s; oracle/mfcc_oracle.c with its float32 FFT, %s build"
