@@ -1292,18 +1292,26 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
                         x0 = (float)(int)(short)(d & 0xffffu);
                         x1 = (float)((int)d >> 16);
                     } else if (ch_n == 2) {
-                        // interleaved stereo: sample s is one aligned 32-bit word (L | R << 16); mono = (L + R) >> 1
-                        const uint32_t *w32 = (const uint32_t *)p.pcm + (s0 + 2 * n);
-                        const uint32_t d0 = w32[0];
+                        // interleaved stereo: sample s is one aligned 32-bit word (L | R << 16); mono = (L + R) >> 1.
+                        // The pair (s, s + 1) comes as ONE 8-byte load at 4-byte alignment (consecutive lanes then
+                        // cover 512 contiguous bytes); an odd window's last pair re-reads its own sample instead
+                        // of the one past the frame.
+                        struct __attribute__((aligned(4))) Pair32 {
+                            uint32_t x, y;
+                        };
+                        const bool has1 = 2 * n + 1 < W;
+                        const uint32_t *w32 = (const uint32_t *)p.pcm + (s0 + 2 * n) - (has1 ? 0 : 1);
+                        const Pair32 dd = *(const Pair32 *)w32;
+                        const uint32_t d0 = has1 ? dd.x : dd.y, d1 = dd.y;
                         x0 = (float)(((int)(short)(d0 & 0xffffu) + ((int)d0 >> 16)) >> 1);
-                        if (2 * n + 1 < W) {
-                            const uint32_t d1 = w32[1];
-                            x1 = (float)(((int)(short)(d1 & 0xffffu) + ((int)d1 >> 16)) >> 1);
-                        }
+                        if (has1) x1 = (float)(((int)(short)(d1 & 0xffffu) + ((int)d1 >> 16)) >> 1);
                     } else {
-                        const int64_t s = s0 + 2 * n;
-                        x0 = (float)(int)p.pcm[s];
-                        if (2 * n + 1 < W) x1 = (float)(int)p.pcm[s + 1];
+                        // mono at an odd sample offset: the pair as ONE 4-byte load at 2-byte alignment
+                        typedef uint32_t __attribute__((aligned(2))) u32_a2;
+                        const bool has1 = 2 * n + 1 < W;
+                        const uint32_t d = *(const u32_a2 *)(p.pcm + s0 + 2 * n - (has1 ? 0 : 1));
+                        x0 = (float)(int)(short)(has1 ? (d & 0xffffu) : (d >> 16));
+                        if (has1) x1 = (float)((int)d >> 16);
                     }
                 }
                 const float2 w = s_win[n];
