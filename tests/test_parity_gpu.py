@@ -838,3 +838,34 @@ def test_fused_delta_many_blocks_full_shape(pkg, orc, monkeypatch):
     assert np.array_equal(m_f.batch_run_host(pcm), a)
     want = orc.run_utterance(cfg, pcm[7 * n:8 * n], w, bug_compat=False)
     assert_close(a[7 * 998:8 * 998], want, "utt 7", groups=3)
+
+
+@pytest.mark.parametrize("fft", [0, 1024])
+def test_batch_replan_and_alpha_change_between_runs(pkg, orc, fft):
+    """One handle, several batches: a new plan (other lengths, fewer utterances) and a new VTLN factor between
+    runs must rebuild whatever depends on them (mel tables, lane / work plans, LDS sizes) -- 512-point register
+    kernel and the long-transform kernel."""
+    kw = dict(nb=40) if fft == 0 else dict(nb=80, W=1024, S=256)   # (a full-length window: same frame count as the oracle)
+    m, cfg, w = make_pair(pkg, orc, 200000, dyn=2, **kw)
+    assert m.fft_size() == (fft or 512)
+
+    def check(lens, alpha, tag):
+        offs, pos = [], 0
+        for n in lens:
+            offs.append(pos)
+            pos += n + (n & 1)
+        pcm = np.zeros(pos + 8, np.int16)
+        for u, (o_, n) in enumerate(zip(offs, lens)):
+            pcm[o_:o_ + n] = synth_utterance(n, 300 + u)
+        m.set_alpha(alpha)
+        rows, total = m.batch_plan(offs, lens)
+        got = m.batch_run_host(pcm)
+        for u, n in enumerate(lens):
+            want = orc.run_utterance(cfg, pcm[offs[u]:offs[u] + n], w, alpha=alpha, bug_compat=False)
+            T = want.shape[0]
+            assert_close(got[rows[u]:rows[u] + T], want, "%s utt %d" % (tag, u), groups=3)
+
+    check([48000, 16000, 30000], 1.0, "first plan")
+    check([20000, 64000], 0.9, "second plan, alpha 0.9")
+    check([48000, 16000, 30000, 8000], 1.1, "third plan, alpha 1.1")
+    check([48000], 1.0, "back to alpha 1")
