@@ -1230,7 +1230,9 @@ __device__ __forceinline__ void stockham_pass(float2 *buf, const float2 *s_tw, i
     wave_sync();
 }
 
-template <int LOG2M, bool FUSED, bool PAIR>
+// HALF: the window is at most M samples (a short window zero padded to the transform, BASELINE configs[2]): the
+// upper half of every lane's sample pairs is zero at compile time and pass 1 sheds the arithmetic on it.
+template <int LOG2M, bool FUSED, bool PAIR, bool HALF>
 __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 512 : 1024) k_front_reg(FrontParams p)
 {
     constexpr int M = 1 << LOG2M, NV = M / 64;
@@ -1285,6 +1287,10 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int n = lane + 64 * j;
+                if (HALF && j >= NV / 2) { // 2 n >= M >= W: no taps here
+                    v[j] = make_float2(0.f, 0.f);
+                    continue;
+                }
                 float x0 = 0.f, x1 = 0.f;
                 if (2 * n < W) {
                     if (PAIR) {
@@ -1758,23 +1764,33 @@ int front_reg_waves(const FrontParams &p, bool fused)
     return 0;
 }
 
+template <int LOG2M, bool FUSED, bool PAIR, bool HALF>
+hipError_t launch_reg_inst(const FrontParams &p, int nw, size_t lds, int blocks, hipStream_t stream)
+{
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_front_reg<LOG2M, FUSED, PAIR, HALF>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_front_reg<LOG2M, FUSED, PAIR, HALF>), dim3(blocks), dim3(64 * nw), lds, stream, p);
+    return hipGetLastError();
+}
+
 template <int LOG2M, bool FUSED>
 hipError_t launch_reg(const FrontParams &p, int nw, hipStream_t stream)
 {
     const size_t lds = front_reg_lds_floats(p, FUSED, nw) * sizeof(float);
-    const void *fn = p.pair_ok ? (const void *)k_front_reg<LOG2M, FUSED, true> : (const void *)k_front_reg<LOG2M, FUSED, false>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
     int blocks = (p.n_chunks + nw - 1) / nw;
     const int cap = num_cus() * (lds * 2 <= 160 * 1024 && nw <= 16 ? 2 : 1);
     if (blocks > cap) blocks = cap;
-    if (p.pair_ok)
-        hipLaunchKernelGGL((k_front_reg<LOG2M, FUSED, true>), dim3(blocks), dim3(64 * nw), lds, stream, p);
-    else
-        hipLaunchKernelGGL((k_front_reg<LOG2M, FUSED, false>), dim3(blocks), dim3(64 * nw), lds, stream, p);
-    return hipGetLastError();
+    // the half-window build exists for 1024 points only (25 ms at 16 kHz zero padded to 1024: BASELINE configs[2])
+    if (LOG2M == 9 && p.window_size <= (1 << LOG2M)) {
+        constexpr bool H = LOG2M == 9;
+        return p.pair_ok ? launch_reg_inst<LOG2M, FUSED, true, H>(p, nw, lds, blocks, stream)
+                         : launch_reg_inst<LOG2M, FUSED, false, H>(p, nw, lds, blocks, stream);
+    }
+    return p.pair_ok ? launch_reg_inst<LOG2M, FUSED, true, false>(p, nw, lds, blocks, stream)
+                     : launch_reg_inst<LOG2M, FUSED, false, false>(p, nw, lds, blocks, stream);
 }
 
 } // namespace
