@@ -73,8 +73,7 @@ struct mfx_handle {
     DevBuf<float> d_mel_item_w, d_sweep_item_w;
     int mel_K = 0, mel_wlen = 0, sweep_wlen = 0;
     // 512-point kernel: per-lane mel plan + transposed DCT matrix
-    DevBuf<float> d_mel_lane_w, d_dct_t, d_dct_lane_w;
-    int dct_lane_stride = 0;
+    DevBuf<float> d_mel_lane_w, d_dct_t;
     DevBuf<int32_t> d_mel_lane_start, d_mel_lane_fid;
     MelLanePlan plan;
     int dct_stride = 0, nb_pad = 0;
@@ -197,11 +196,6 @@ int refresh_mel(mfx_handle *h)
     h->fused_ok = false;
     if (h->fast512 && build_mel_lane_plan(t, h->nb, h->W2, /*max_read_bin=*/511 - 32, h->plan)) {
         HIP_TRY(h, upload(h->d_mel_lane_w, h->plan.w));
-        if (h->ceps > 0 && h->cols <= 16) { // fused mel + DCT with the DPP reduction
-            std::vector<float> rows;
-            build_dct_lane_rows(h->plan, h->h_dct, h->dl, h->dct_lane_stride, rows);
-            HIP_TRY(h, upload(h->d_dct_lane_w, rows));
-        }
         HIP_TRY(h, upload(h->d_mel_lane_start, h->plan.start));
         HIP_TRY(h, upload(h->d_mel_lane_fid, h->plan.fid));
         FrontParams probe;
@@ -245,9 +239,8 @@ void fill_front(const mfx_handle *h, FrontParams &p)
     p.mel_rounds = h->plan.rounds;
     p.mel_row_stride = h->plan.row_stride;
     for (int i = 0; i < 8; ++i) p.mel_L[i] = h->plan.L[i];
-    p.dct_lane_w = h->d_dct_lane_w.p;
-    p.dct_mode = (h->ceps > 0 && h->cols <= 16 && h->d_dct_lane_w.p) ? 1 : 0;
-    p.dct_stride = p.dct_mode == 1 ? h->dct_lane_stride : h->dct_stride;
+    p.dct_mode = (h->ceps > 0 && h->cols <= 16 && h->nb <= 40) ? 1 : 0; // DCT on the matrix pipe
+    p.dct_stride = h->dct_stride;
     p.nb_pad = h->nb_pad > 0 ? h->nb_pad : ((h->nb + 3) & ~3);
 }
 
@@ -365,7 +358,6 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_sweep_pieces.release();
     h->d_mel_lane_w.release();
     h->d_dct_t.release();
-    h->d_dct_lane_w.release();
     h->d_mel_lane_start.release();
     h->d_mel_lane_fid.release();
     h->d_carry[0].release();

@@ -82,8 +82,8 @@ struct FrontParams {
     const int32_t *mel_lane_start;// [mel_rounds][16] first bin of the lane's filter in that round
     const int32_t *mel_lane_fid;  // [mel_rounds][16] filter index or -1
     const float *dct_t;           // [cols][dct_stride] transposed DCT matrix, rows zero padded to nb_pad
-    const float *dct_lane_w;      // [16][dct_stride] per-lane DCT rows, one 16-float group per round (dct_mode 1)
-    int32_t dct_mode;             // 0: DCT from the LDS mel scratch; 1: fused into the mel rounds + DPP reduce (cols <= 16)
+    int32_t dct_mode;             // 0: DCT from the LDS mel scratch; 1: on the matrix pipe, v_mfma_f32_16x16x4_f32 per
+                                  //    4 frames (cols <= 16, num_banks <= 40; matrix from `dct`, held in registers)
     int32_t mel_rounds, mel_row_stride, dct_stride, nb_pad;
     int32_t mel_L[8];
     int32_t num_banks;

@@ -232,43 +232,9 @@ __device__ __forceinline__ float row_partner(float x)
     return __int_as_float(t);
 }
 
-template <int CTRL, int BANK_MASK>
-__device__ __forceinline__ float dpp_mov(float old, float x)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), CTRL, 0xf, BANK_MASK, false));
-}
-
-// Sum 16 values over the 16 lanes of a DPP row; lane c returns the total of v[c].
-// Butterfly: at distance 1, 2, 4, 8 each lane keeps the half of its values whose index bit equals
-// its own lane bit and adds the partner's copy of that half.
-__device__ __forceinline__ float row_reduce16(const float (&v)[16], int l)
-{
-    const bool b0 = l & 1, b1 = l & 2, b2 = l & 4, b3 = l & 8;
-    float w[8], x[4], y[2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float keep = b0 ? v[2 * i + 1] : v[2 * i];
-        const float send = b0 ? v[2 * i] : v[2 * i + 1];
-        w[i] = keep + dpp_mov<0xB1, 0xf>(0.f, send); // quad_perm [1,0,3,2]: lane ^ 1
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float keep = b1 ? w[2 * i + 1] : w[2 * i];
-        const float send = b1 ? w[2 * i] : w[2 * i + 1];
-        x[i] = keep + dpp_mov<0x4E, 0xf>(0.f, send); // quad_perm [2,3,0,1]: lane ^ 2
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float keep = b2 ? x[2 * i + 1] : x[2 * i];
-        const float send = b2 ? x[2 * i] : x[2 * i + 1];
-        float t = dpp_mov<0x104, 0x5>(0.f, send);   // row_shl:4 into banks 0,2: from lane + 4
-        t = dpp_mov<0x114, 0xA>(t, send);           // row_shr:4 into banks 1,3: from lane - 4
-        y[i] = keep + t;
-    }
-    const float keep = b3 ? y[1] : y[0];
-    const float send = b3 ? y[0] : y[1];
-    return keep + dpp_mov<0x128, 0xf>(0.f, send);   // row_ror:8: lane ^ 8
-}
+// DCT on the matrix pipe (dct_mode 1): K steps of v_mfma_f32_16x16x4_f32 over the mel bands, 4 bands per step
+constexpr int kDctSteps = 10;  // num_banks <= 40
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <bool ALIGNED, int NM>
 struct PcmRegs {
@@ -578,7 +544,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
     int *s_mstart = (int *)(s_melw + 16 * RS);       // [rounds][16]
     int *s_mfid = s_mstart + 16 * rounds;            // [rounds][16]
     float *s_dct = (float *)(s_mfid + 16 * rounds);  // [cols][DS]
-    const int dct_floats = p.dct ? (p.dct_mode == 1 ? 16 : cols) * DS : 0;
+    const int dct_floats = (p.dct && p.dct_mode != 1) ? cols * DS : 0; // dct_mode 1 keeps its matrix in registers
     float *s_wave = s_dct + dct_floats + wave * (4 * kSlot);
     float *xb = s_wave + slot * kSlot;
     // FUSE: the last wave runs the delta stage; its region starts at its (unused) frame slots
@@ -604,7 +570,14 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
             s_mstart[i] = p.mel_lane_start[i];
             s_mfid[i] = p.mel_lane_fid[i];
         }
-        for (int i = tid; i < dct_floats; i += kThreads) s_dct[i] = (p.dct_mode == 1 ? p.dct_lane_w : p.dct_t)[i];
+        for (int i = tid; i < dct_floats; i += kThreads) s_dct[i] = p.dct_t[i];
+    }
+    // dct_mode 1: B operand of K step j on lane (k = slot, n = l) is dct[4 j + k][n]; zeros beyond the matrix
+    float dctb[kDctSteps];
+#pragma unroll
+    for (int j = 0; j < kDctSteps; ++j) {
+        const int m = 4 * j + slot;
+        dctb[j] = (!TO_SPEC && p.dct_mode == 1 && m < p.num_banks && l < p.dct_len) ? p.dct[m * p.dct_len + l] : 0.f;
     }
     // the slots are read (times zero weights) before every word has been written once: make them finite
     for (int i = lane; i < 4 * kSlot; i += 64) s_wave[i] = 0.f;
@@ -821,31 +794,46 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
 #endif
 
             MFX_STAMP(4);
-            // ---- real split + magnitude
-            float mag[16];
+            // ---- real split + magnitude, one partner fetch per bin PAIR (k, 256 - k), k = l + 16 p, p < 8:
+            //   S = Z[k] + conj Z[256-k], T = (-i W_512^k)(Z[k] - conj Z[256-k]):  X[k] = S + T,  X[256-k] = conj(S - T)
+            // (the twiddle of bin 256 - k is the conjugate of bin k's).  The partner Z[256 - k] is register 15 - p of
+            // lane (16 - l) % 16; lane 0 pairs with itself one register further (bin 16 p <-> bin 16 (16 - p)), so the
+            // partner registers are taken from a copy that lane 0 holds shifted by one: the exchange itself is then
+            // the same two DPP moves on every lane.  Lane l ends with its own bins p < 8 and the bins of lane
+            // (16 - l) % 16 for p >= 8 -- both go straight to their places (LDS or HBM), no second exchange.
+            // Lane 0, p = 0 pairs bin 0 with the Nyquist bin 256 = Z[0] again: X[256] = Re Z[0] - Im Z[0] falls out
+            // of the same formula; its self-paired bin 128 = conj-scaled Z[128] is done on the side.
+            float mag_k[8], mag_p[8];
 #if defined(MFX_ABLATE) && MFX_ABLATE >= 2
 #pragma unroll
-            for (int pp = 0; pp < 16; ++pp) mag[pp] = a[pp].x + a[pp].y;
-            const float nyq = 0.f;
+            for (int pp = 0; pp < 8; ++pp) {
+                mag_k[pp] = a[pp].x + a[pp].y;
+                mag_p[pp] = a[15 - pp].x + a[15 - pp].y;
+            }
+            const float mag128 = 0.f;
 #else
+            float2 bsh[8];
 #pragma unroll
-            for (int pp = 0; pp < 16; ++pp) {
-                // partner value Z[256 - k]: lane (16-l)%16, register 15-pp (lane 0: register (16-pp)%16)
-                float zr = row_partner(a[15 - pp].x);
-                float zi = row_partner(a[15 - pp].y);
-                if (l == 0) {
-                    zr = a[(16 - pp) & 15].x;
-                    zi = a[(16 - pp) & 15].y;
-                }
+            for (int j = 0; j < 8; ++j) {
+                bsh[j].x = l == 0 ? a[(9 + j) & 15].x : a[8 + j].x;
+                bsh[j].y = l == 0 ? a[(9 + j) & 15].y : a[8 + j].y;
+            }
+            const float m128r = a[8].x + a[8].x, m128i = a[8].y + a[8].y;
+            const float mag128 = __builtin_amdgcn_sqrtf(m128r * m128r + m128i * m128i);
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp) {
+                const float zr = row_partner(bsh[7 - pp].x);
+                const float zi = row_partner(bsh[7 - pp].y);
                 const float2 cs = lds_read_b64(s_split + l + 16 * pp);
                 const float sr = a[pp].x + zr, si = a[pp].y - zi;
                 const float dr = a[pp].x - zr, di = a[pp].y + zi;
-                const float xr = sr + (cs.x * dr - cs.y * di);
-                const float xi = si + (cs.x * di + cs.y * dr);
-                mag[pp] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi); // the window taps carry 0.5 / W2
+                const float tr = cs.x * dr - cs.y * di;
+                const float ti = cs.x * di + cs.y * dr;
+                const float xr = sr + tr, xi = si + ti;
+                const float yr = sr - tr, yi = si - ti;
+                mag_k[pp] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi); // the window taps carry 0.5 / W2
+                mag_p[pp] = __builtin_amdgcn_sqrtf(yr * yr + yi * yi);
             }
-            // Nyquist bin: X[256] = Re Z[0] - Im Z[0]
-            const float nyq = 2.0f * fabsf(a[0].x - a[0].y);
 #endif
 
             MFX_STAMP(5);
@@ -853,15 +841,18 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
                 if (live) {
                     float *dst = p.spec + (out_row + f) * (int64_t)p.spec_pitch;
 #pragma unroll
-                    for (int pp = 0; pp < 16; ++pp) dst[l + 16 * pp] = mag[pp];
-                    if (l == 0) dst[256] = nyq;
+                    for (int pp = 0; pp < 8; ++pp) {
+                        dst[l + 16 * pp] = mag_k[pp];
+                        dst[256 - l - 16 * pp] = mag_p[pp];
+                    }
+                    if (l == 0) dst[128] = mag128;
                 }
             } else {
 #if defined(MFX_ABLATE) && MFX_ABLATE >= 1
                 {   // dev-only: stop after the magnitudes, keep them live
-                    float acc = nyq;
+                    float acc = mag128;
 #pragma unroll
-                    for (int pp = 0; pp < 16; ++pp) acc += mag[pp];
+                    for (int pp = 0; pp < 8; ++pp) acc += mag_k[pp] + mag_p[pp];
                     float *dstx = p.feat + (out_row + (live ? f : 0)) * (int64_t)p.feat_pitch;
                     if (live && l < cols) dstx[l] = acc;
                     continue;
@@ -870,9 +861,14 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
                 // odd slots keep their magnitudes 32 dwords further in: the two slots of a 32-lane
                 // LDS access group then sit on complementary bank pairs for the b64 mel reads
                 float *mg0 = xb + 32 * (slot & 1);
+                {
+                    float *mlo = mg0 + l, *mhi = mg0 + (144 - l); // bins l + 16 p and 256 - l - 16 p = (144 - l) + 16 (7 - p)
 #pragma unroll
-                for (int pp = 0; pp < 16; ++pp) mg0[l + 16 * pp] = mag[pp];
-                if (l == 0) mg0[256] = nyq;
+                    for (int pp = 0; pp < 8; ++pp) mlo[16 * pp] = mag_k[pp];
+#pragma unroll
+                    for (int pp = 0; pp < 8; ++pp) mhi[16 * pp] = mag_p[7 - pp];
+                    if (l == 0) mg0[128] = mag128;
+                }
                 wave_sync();
 
                 // ---- mel filterbank: per round every lane walks one filter's bins in ascending
@@ -883,21 +879,18 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
                 const float *wrow = s_melw + l * RS;
                 float *dst = p.feat + (out_row + (live ? f : 0)) * (int64_t)p.feat_pitch;
                 if (p.dct_mode == 1) {
-                    // DCT-II + lifter fused into the mel rounds: lane j adds its filter's log energy
-                    // times row fid of the DCT matrix into 16 per-lane partial sums, which a 4-step
-                    // DPP butterfly then reduces over the frame's 16 lanes (lane c ends with output c).
-                    // Round lengths are multiples of 16 bins: each trip issues its 12 LDS reads back to
-                    // back before the 16 dependent FMAs, so the read latency is paid once per trip.
-                    float part[16];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) part[c] = 0.f;
-                    const float *drow = s_dct + l * DS;
+                    // log mel energies to the frame's LDS row (8 dwords of skew per slot: the operand reads below
+                    // then fall on distinct banks), then the DCT-II + lifter (mfcccpu.cpp:222-232) as ONE chain of
+                    // f32 matrix instructions per 4 frames on the otherwise idle matrix pipe:
+                    //   D[row][c] = sum_m A[row][m] B[m][c],  v_mfma_f32_16x16x4_f32, K step j covers m = 4j .. 4j+3,
+                    // bit for bit an fmaf chain in ascending m.  Frame `slot` sits in rows 4 slot .. 4 slot + 3 (four
+                    // copies: all 64 lanes read valid energies), so register 0 of the result is out[slot][c] on
+                    // lane (slot, c) -- exactly the lane that stores it.
+                    float *lm = xb + kMelOff + 8 * slot;
                     for (int r = 0; r < rounds; ++r) {
                         const int L = p.mel_L[r];
                         const float *mg = mg0 + s_mstart[r * 16 + l];
-                        float4 dv[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) dv[q] = *(const float4 *)(drow + r * 16 + 4 * q);
+                        const int fid = s_mfid[r * 16 + l];
                         float acc = 0.f;
                         for (int s = 0; s < L; s += 8) {
                             float4 w[2];
@@ -915,18 +908,17 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
                             }
                         }
                         wrow += L;
-                        const float e = MFX_LOG(fmaxf(acc, 1e-30f));
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            part[4 * q + 0] += e * dv[q].x;
-                            part[4 * q + 1] += e * dv[q].y;
-                            part[4 * q + 2] += e * dv[q].z;
-                            part[4 * q + 3] += e * dv[q].w;
-                        }
+                        lm[fid >= 0 ? fid : 4 * kDctSteps] = MFX_LOG(fmaxf(acc, 1e-30f)); // idle lane: a word nobody reads
                     }
-                    const float outv = row_reduce16(part, l);
+                    wave_sync();
+                    const float *arow = s_wave + (l >> 2) * (kSlot + 8) + kMelOff + slot; // A[row l][k = slot] of K step 0
+                    f32x4 dacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < kDctSteps; ++j)
+                        dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * j], dctb[j], dacc, 0, 0, 0);
+                    const float outv = dacc[0];
                     // pitch 16 = compact static scratch: write whole 64-byte rows (zeros beyond cols)
-                    if (live && (l < cols || p.feat_pitch == 16)) dst[l] = l < cols ? outv : 0.f;
+                    if (live && (l < cols || p.feat_pitch == 16)) dst[l] = outv;
                 } else {
                     float *melbuf = xb + kMelOff;
                     for (int r = 0; r < rounds; ++r) {
@@ -1649,7 +1641,7 @@ size_t front512_lds_bytes(const FrontParams &p)
     size_t f = 512 + 512 + 2 * 264;                      // window pairs, pass twiddles, split twiddles
     f += (size_t)16 * p.mel_row_stride;                  // per-lane mel weights
     f += (size_t)32 * p.mel_rounds;                      // per-lane bin starts + filter ids
-    f += p.dct ? (size_t)(p.dct_mode == 1 ? 16 : p.cols) * p.dct_stride : 0; // DCT table (either layout)
+    f += (p.dct && p.dct_mode != 1) ? (size_t)p.cols * p.dct_stride : 0; // transposed DCT table (dct_mode 0)
     f += kWaves * 4 * kSlot;                             // 4 frame slots per wave
     f += 4;                                              // block-local work counter
     return f * sizeof(float);

@@ -168,20 +168,6 @@ bool build_mel_lane_plan(const MelTable &t, int num_banks, int fft_size, int max
     return true;
 }
 
-void build_dct_lane_rows(const MelLanePlan &plan, const std::vector<float> &dct, int dct_len, int &stride,
-                         std::vector<float> &out)
-{
-    stride = stride_4odd(plan.rounds * 16);
-    out.assign((size_t)16 * stride, 0.0f);
-    for (int r = 0; r < plan.rounds; ++r)
-        for (int j = 0; j < 16; ++j) {
-            const int m = plan.fid[r * 16 + j];
-            if (m < 0) continue;
-            for (int c = 0; c < dct_len && c < 16; ++c)
-                out[(size_t)j * stride + r * 16 + c] = dct[(size_t)m * dct_len + c];
-        }
-}
-
 void build_dct_transposed(const std::vector<float> &dct, int num_banks, int dct_len, int &stride, int &nb_pad,
                           std::vector<float> &out)
 {

@@ -58,11 +58,6 @@ struct MelLanePlan {
 // would read past `max_read_bin`)
 bool build_mel_lane_plan(const MelTable &t, int num_banks, int fft_size, int max_read_bin, MelLanePlan &out);
 
-// Per-lane DCT rows for the fused mel+DCT path: lane j, round r -> the 16-float group
-// out[j * stride + 16 r ..] = row fid(r, j) of the [num_banks][dct_len] matrix (zeros if idle).
-void build_dct_lane_rows(const MelLanePlan &plan, const std::vector<float> &dct, int dct_len, int &stride,
-                         std::vector<float> &out);
-
 // Transposed, padded DCT matrix for the 512-point kernel: [cols][stride], stride / 4 odd,
 // row c = column c of the [num_banks][dct_len] matrix followed by zeros.
 void build_dct_transposed(const std::vector<float> &dct, int num_banks, int dct_len, int &stride, int &nb_pad,

@@ -32,6 +32,9 @@ WORKLOADS = {
     # name: (n_utt, utt_samples, sample_rate, W, S, fft, nb, nc, dyn)
     "C2": dict(n_utt=1000, utt_samples=160000, sr=16000.0, W=400, S=160, fft=0, nb=40, nc=13, dyn=2,
                desc="1000 synthetic 16 kHz utterances x 10 s, 25 ms/10 ms, 512-pt FFT, 40 mel, 13 MFCC + d + dd"),
+    "C4": dict(n_utt=12500, utt_samples=160000, sr=16000.0, W=400, S=160, fft=0, nb=40, nc=13, dyn=2,
+               desc="per-GPU share of 100 000 synthetic 16 kHz utterances x 10 s sharded round-robin over 8 GPUs "
+                    "(12 500 utterances, 4 GB of PCM per GPU), 512-pt FFT, 40 mel, 13 MFCC + d + dd"),
     "T": dict(n_utt=8, utt_samples=16000, sr=16000.0, W=400, S=160, fft=0, nb=40, nc=13, dyn=2,
               desc="tiny test workload: 8 synthetic 16 kHz utterances x 1 s (launch-path tests only)"),
     "C3": dict(n_utt=1, utt_samples=57600000, sr=16000.0, W=400, S=160, fft=1024, nb=80, nc=13, dyn=0,
@@ -78,18 +81,32 @@ def host_cpu_share():
             break
         except Exception:
             continue
+    how = "min(affinity mask, cgroup CPU quota) = %d" % n
     env = os.environ.get("MFX_CPU_THREADS")
     if env:
         n = max(1, int(env))
+        how = "MFX_CPU_THREADS=%d" % n
     elif n > 64:
-        n = 16  # no quota visible on a many-core host: a 1-GPU box's documented CPU share
-    return n
+        # no quota visible on a many-core host: a 1-GPU box is granted 16 CPUs of the host (the pool's documented share)
+        how = "capped to 16 (the 1-GPU box's CPU share): no cgroup quota visible, %d CPUs in the affinity mask" % n
+        n = 16
+    return n, how
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(orc, wl, pcm_host, window, budget_s=12.0):
     """Oracle (kind "port") timed on this host's cores over a bounded sample of the same workload."""
     import ctypes
-    cores = host_cpu_share()
+    cores, cores_how = host_cpu_share()
     # a -march=native build of the same source if the compiler is here; else the portable one
     libpath = None
     try:
@@ -143,6 +160,7 @@ def cpu_baseline(orc, wl, pcm_host, window, budget_s=12.0):
     return {
         "fft_stage_proxy": fft_proxy,
         "value": rall, "unit": "frames/s", "cores": cores, "kind": "port",
+        "cores_derivation": cores_how, "os_cpu_count": os.cpu_count(), "cpu_model": cpu_model(),
         "sample": "%d utterances of the workload x %d passes = %d frames on all %d host threads (OpenMP, one "
                   "extractor per thread, setup untimed), %.1f s; oracle/mfcc_oracle.c with its float32 FFT, %s build"
                   % (n_all, reps, fall, cores, dtall, "-march=native" if libpath else "portable -mavx2"),
@@ -155,14 +173,45 @@ def wl_frames(wl):
     return per * wl["n_utt"]
 
 
+def spawn_ranks(args):
+    """`bench.py --gpus N` without an external launcher: start the N ranks as children (one process per GPU under
+    torch.distributed.run), relay rank 0's JSON line and return the children's status.  Runs BEFORE anything in
+    this process touches the GPU (torch is not even imported yet)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if r.returncode != 0 or line is None:
+        sys.stderr.write(r.stdout[-4000:])
+        return r.returncode or 1
+    if json.loads(line).get("n_gpus") != args.gpus:
+        sys.stderr.write("bench.py: the launched job reported n_gpus != --gpus\n")
+        return 1
+    print(line)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # Defaults long enough to measure the steady state: for the first ~10 ms of sustained load an MI355X is still
-    # raising its clocks (a 3 + 20 step run reads 0.58 ms/step where 50 + 500 reads 0.49; profiles/r01/README.md).
-    # 550 steps of the C2 workload are ~0.3 s of GPU time.
+    # The headline does not depend on these two: an untimed settle phase (--settle-ms of GPU work, reported as
+    # settle_ms) runs before the warm-up steps, because for the first ~10 ms of sustained load an MI355X is still
+    # raising its clocks (a bare 5 + 20 step run reads 15 % slower than 50 + 500; profiles/r01/README.md).
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--settle-ms", type=float, default=100.0,
+                    help="run untimed steps until this much wall time of back-to-back GPU work has passed (0: off)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true",
@@ -170,13 +219,16 @@ def main():
                          "neutral on MI355X -- the front end's waves fill the register file -- so off by default")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
     # test knobs (rehearsing the N>1 path on a 1-GPU box): MFX_BENCH_DEVICE pins every rank to one
@@ -199,8 +251,7 @@ def main():
     W, S = wl["W"], wl["S"]
     window = pkg.reference_window(W)
 
-    # ---- extractor and batch plan first (they need only the sizes), then the synthetic input: the data generation
-    # keeps the GPU busy right up to the first warm-up step, so even a short --warmup starts on raised clocks
+    # ---- extractor and batch plan first (they need only the sizes), then the synthetic input
     channels = wl.get("channels", 1)
     m = pkg.MfccHip(wl["utt_samples"] + 1000, W, S, wl["nb"], wl["sr"], 64.0, wl["sr"] / 2, wl["nc"], False, 22.0,
                     pkg.NORM_NONE, wl["dyn"], 3, 3, True, device=dev_index, fft_size=wl["fft"], channels=channels)
@@ -222,6 +273,24 @@ def main():
     def step():
         m.batch_run_device(pcm.data_ptr(), n_samples, out.data_ptr())
 
+    # settle: untimed back-to-back steps until the clocks have stopped rising (time based, so the headline does not
+    # depend on the caller's step counts); batches of steps are queued without a host sync in between
+    settle_ms, settle_steps = 0.0, 0
+    if args.settle_ms > 0:
+        step()
+        m.synchronize()
+        t_s = time.perf_counter()
+        step()
+        m.synchronize()
+        one = max(time.perf_counter() - t_s, 1e-5)
+        burst = int(max(1, min(1000, 0.01 / one)))       # ~10 ms of queued work per host sync
+        t_s = time.perf_counter()
+        while (time.perf_counter() - t_s) * 1e3 < args.settle_ms:
+            for _ in range(burst):
+                step()
+            m.synchronize()
+            settle_steps += burst
+        settle_ms = (time.perf_counter() - t_s) * 1e3
     for _ in range(args.warmup):
         step()
     m.synchronize()
@@ -261,18 +330,23 @@ def main():
     avg_kernel_ms = kernel_ms / max(launches, 1)
     launches_per_step = max(launches, 1) / args.steps
     achieved = (kernel_bytes_per_frame * frames_rank / launches_per_step) / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0
-    traffic = None
+    # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, collected in their own rocprofv3 --pmc runs of
+    # this same command and corrected as MI355X_MICROARCH.md prescribes): NOT measured in this run -- read from the
+    # tracked profiles/traffic_latest.json, per workload and kernel, and labelled so
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("workload") == args.workload and tj.get("kernel") == kname:
-                traffic = tj.get("hbm_bytes_per_launch")
+            ent = tj.get(args.workload) if isinstance(tj.get(args.workload), dict) else tj
+            if ent.get("workload", args.workload) == args.workload and ent.get("kernel") == kname:
+                traffic = ent.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/traffic_latest.json (%s)" % ent.get("source", "rocprofv3 --pmc passes")
         except Exception:
             traffic = None
     roofline = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
         "kernel": kname, "kernel_avg_ms": avg_kernel_ms, "kernel_launches_per_step": launches_per_step,
         "algorithmic_bytes_per_frame": kernel_bytes_per_frame,
         "whole_path": {"bytes_per_frame": path_bytes_per_frame,
@@ -284,6 +358,7 @@ def main():
         "metric": "audio frames/sec (16 kHz, 25 ms/10 ms, 512-pt FFT, 40 mel, 13 MFCC + delta + delta-delta)"
                   if args.workload == "C2" else "audio frames/sec (%s)" % wl["desc"],
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "settle_ms": settle_ms, "settle_steps": settle_steps,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %s; per GPU, resident in HBM" % (args.workload, wl["desc"]),

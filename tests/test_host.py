@@ -235,3 +235,15 @@ def test_sphere_and_riff_fixtures_hold_the_same_pcm(orc):
     sph = np.frombuffer(raw[1024:1024 + 2 * 54682], dtype="<i2")
     pcm, sr = orc.read_wav_pcm16(os.path.join(GOLDEN, "sample1_riff.wav"))
     assert sr == 16000 and np.array_equal(pcm[:, 0], sph)
+
+
+def test_bench_refuses_rank_count_mismatch():
+    """bench.py never reports a line whose n_gpus differs from --gpus: under a launcher that started a different
+    number of ranks it stops (checked before any GPU use, so this runs without a GPU)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 4" in r.stderr and "{" not in r.stdout

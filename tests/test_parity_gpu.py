@@ -694,6 +694,27 @@ def test_bench_two_rank_launch_path(tmp_path):
     assert "roofline" in d and "cpu_baseline" not in d
 
 
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` with NO external launcher: the parent starts the two ranks itself (before it touches
+    the GPU), relays rank 0's single JSON line and reports n_gpus == 2 (the reference's analogue is
+    the sequential file queue, ASR_OCL.cpp:340-368)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MFX_BENCH_DEVICE="0", MFX_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--settle-ms", "5", "--workload", "T", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["settle_ms"] >= 5
+    assert abs(d["value"] - 2 * 8 * 98 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
 # ---------------------------------------------------------------------------------------------
 # randomized configuration sweep (seeded): window/shift/filterbank/cepstra/delta/normalisation shapes
 # the fixed cases above do not hit -- odd shifts, windows that are not multiples of 32, FFT overrides,
