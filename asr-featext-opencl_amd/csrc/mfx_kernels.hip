@@ -34,6 +34,16 @@ __device__ __forceinline__ float2 lds_read_b64(const float2 *p)
     return v;
 }
 
+// 16-byte LDS read kept whole (the optimiser otherwise splits a read whose halves are used apart and re-pairs the
+// pieces as ds_read2_b64, which costs twice the LDS cycles of ds_read_b128)
+__device__ __forceinline__ float4 lds_read_b128(const float4 *p)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f v = *(const v4f *)p;
+    asm("" : "+v"(v)); // (not volatile: free to move)
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 w)
 {
     return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
@@ -223,6 +233,8 @@ constexpr int kSlot = 512;    // dwords per frame slot
 constexpr int kWaves = 16;    // waves per block of the 512-point kernel (one block per CU)
 constexpr int kThreads = kWaves * 64;
 constexpr int kMelOff = 304;  // mel scratch offset inside the slot (after 32 + 257 magnitudes)
+constexpr int kTabStride = 36;   // dwords per lane row of the window / pass-twiddle tables in LDS (16 complex + pad)
+constexpr int kSplitStride = 20; // dwords per lane row of the split-twiddle table (8 complex + pad)
 
 // y[l] = x[(16 - l) & 15] inside every row of 16 lanes: mirror, then rotate right by one
 __device__ __forceinline__ float row_partner(float x)
@@ -234,6 +246,7 @@ __device__ __forceinline__ float row_partner(float x)
 
 // DCT on the matrix pipe (dct_mode 1): K steps of v_mfma_f32_16x16x4_f32 over the mel bands, 4 bands per step
 constexpr int kDctSteps = 10;  // num_banks <= 40
+constexpr int kDctRow = 12;    // dwords per lane row of the B operand table in LDS (16-byte words, disjoint bank quads)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <bool ALIGNED, int NM>
@@ -537,14 +550,19 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
     // ---- LDS carve: shared tables, then one 4-slot region per wave
     const int cols = p.cols;
     const int rounds = p.mel_rounds, RS = p.mel_row_stride, DS = p.dct_stride, nb_pad = p.nb_pad;
-    float2 *s_win = (float2 *)smem;                  // [16 m][16 l]
-    float2 *s_tw = s_win + 256;                      // [16 k][16 l]
-    float2 *s_split = s_tw + 256;                    // [264], natural bin order k = l + 16 p
-    float *s_melw = (float *)(s_split + 264);        // [16][RS]
+    // Lane-major tables: lane l reads ITS window pairs / twiddles as 16-byte words (two complex values per
+    // ds_read_b128, half the LDS instructions of the 8-byte form and whole batches in flight); the row strides
+    // (36 and 20 dwords) put the 16 lanes of a b128 access group on disjoint bank quads.  The 4 frames of a
+    // wave read the same words (broadcast).
+    float *s_win = smem;                             // [16 l][kTabStride]: (w[2n], w[2n+1]), n = l + 16 m, m = 0..15
+    float *s_tw = s_win + 16 * kTabStride;           // [16 l][kTabStride]: W_256^(l k), k = 0..15
+    float *s_split = s_tw + 16 * kTabStride;         // [16 l][kSplitStride]: -i W_512^(l + 16 p), p = 0..7
+    float *s_melw = s_split + 16 * kSplitStride;     // [16][RS]
     int *s_mstart = (int *)(s_melw + 16 * RS);       // [rounds][16]
     int *s_mfid = s_mstart + 16 * rounds;            // [rounds][16]
     float *s_dct = (float *)(s_mfid + 16 * rounds);  // [cols][DS]
-    const int dct_floats = (p.dct && p.dct_mode != 1) ? cols * DS : 0; // dct_mode 1 keeps its matrix in registers
+    // dct_mode 0: transposed matrix [cols][DS]; dct_mode 1: matrix-pipe B operands per lane, [64][kDctRow]
+    const int dct_floats = !p.dct ? 0 : p.dct_mode == 1 ? 64 * kDctRow : cols * DS;
     float *s_wave = s_dct + dct_floats + wave * (4 * kSlot);
     float *xb = s_wave + slot * kSlot;
     // FUSE: the last wave runs the delta stage; its region starts at its (unused) frame slots
@@ -557,27 +575,27 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
     if (FUSE)
         for (int i = tid; i < p.done_words; i += kThreads) s_done[i] = 0u;
 
-    for (int i = tid; i < 256; i += kThreads) {
-        // HBM tables are [lane][m]; the LDS copies are [m][lane]: one instruction reads one row,
-        // 16 consecutive 8-byte words (the 4 frames of a wave read the same words: broadcast)
-        s_win[i] = ((const float2 *)p.winpair)[(i & 15) * 16 + (i >> 4)];
-        s_tw[i] = ((const float2 *)p.twid_pass)[(i & 15) * 16 + (i >> 4)];
+    for (int i = tid; i < 256; i += kThreads) { // HBM tables are [lane][m] as well
+        ((float2 *)(s_win + (i >> 4) * kTabStride))[i & 15] = ((const float2 *)p.winpair)[i];
+        ((float2 *)(s_tw + (i >> 4) * kTabStride))[i & 15] = ((const float2 *)p.twid_pass)[i];
     }
-    for (int i = tid; i < 257; i += kThreads) s_split[i] = ((const float2 *)p.twid_split)[i];
+    for (int i = tid; i < 128; i += kThreads) // bins 0..127, natural order in HBM
+        ((float2 *)(s_split + (i & 15) * kSplitStride))[i >> 4] = ((const float2 *)p.twid_split)[i];
     if (!TO_SPEC) {
         for (int i = tid; i < 16 * RS; i += kThreads) s_melw[i] = p.mel_lane_w[i];
         for (int i = tid; i < 16 * rounds; i += kThreads) {
             s_mstart[i] = p.mel_lane_start[i];
             s_mfid[i] = p.mel_lane_fid[i];
         }
-        for (int i = tid; i < dct_floats; i += kThreads) s_dct[i] = p.dct_t[i];
-    }
-    // dct_mode 1: B operand of K step j on lane (k = slot, n = l) is dct[4 j + k][n]; zeros beyond the matrix
-    float dctb[kDctSteps];
-#pragma unroll
-    for (int j = 0; j < kDctSteps; ++j) {
-        const int m = 4 * j + slot;
-        dctb[j] = (!TO_SPEC && p.dct_mode == 1 && m < p.num_banks && l < p.dct_len) ? p.dct[m * p.dct_len + l] : 0.f;
+        if (p.dct_mode == 1) {
+            // B operand of K step j on lane (k = lane >> 4, n = lane & 15) is dct[4 j + k][n]; zeros beyond the matrix
+            for (int i = tid; i < 64 * kDctRow; i += kThreads) {
+                const int ln = i / kDctRow, j = i - ln * kDctRow, m = 4 * j + (ln >> 4), n = ln & 15;
+                s_dct[i] = (j < kDctSteps && m < p.num_banks && n < p.dct_len) ? p.dct[m * p.dct_len + n] : 0.f;
+            }
+        } else {
+            for (int i = tid; i < dct_floats; i += kThreads) s_dct[i] = p.dct_t[i];
+        }
     }
     // the slots are read (times zero weights) before every word has been written once: make them finite
     for (int i = lane; i < 4 * kSlot; i += 64) s_wave[i] = 0.f;
@@ -743,6 +761,9 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
             // ---- framing + window: z[l + 16m] = (w[2n] x[2n], w[2n+1] x[2n+1])
             float2 a[16];
             const bool odd = !ALIGNED && ((odd0 + f * p.shift) & 1);
+            float4 wq[(NM + 1) / 2];
+#pragma unroll
+            for (int m = 0; m < (NM + 1) / 2; ++m) wq[m] = ((const float4 *)(s_win + l * kTabStride))[m];
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 if (m < NM) {
@@ -755,7 +776,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
                     }
                     const float x0 = (float)(int)(short)(d & 0xffffu);
                     const float x1 = (float)((int)d >> 16);
-                    const float2 w = lds_read_b64(s_win + m * 16 + l);
+                    const float2 w = (m & 1) ? make_float2(wq[m >> 1].z, wq[m >> 1].w) : make_float2(wq[m >> 1].x, wq[m >> 1].y);
                     a[m] = make_float2(w.x * x0, w.y * x1);
                 } else {
                     a[m] = make_float2(0.f, 0.f);
@@ -770,8 +791,17 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
             MFX_STAMP(1);
             // ---- pass A + inter-pass twiddle
             fft16(a);
+            {
+                float4 tq[8];
 #pragma unroll
-            for (int k = 1; k < 16; ++k) a[k] = cmul(a[k], lds_read_b64(s_tw + k * 16 + l));
+                for (int k = 0; k < 8; ++k) tq[k] = lds_read_b128((const float4 *)(s_tw + l * kTabStride) + k);
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) {
+                    const float4 t = tq[k >> 1];
+                    if (k > 0) a[k] = cmul(a[k], make_float2(t.x, t.y));
+                    a[k + 1] = cmul(a[k + 1], make_float2(t.z, t.w));
+                }
+            }
 
             MFX_STAMP(2);
             // ---- 16x16 transpose through the frame slot (XOR swizzle, see above).  Odd slots swap neighbouring
@@ -820,11 +850,14 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
             }
             const float m128r = a[8].x + a[8].x, m128i = a[8].y + a[8].y;
             const float mag128 = __builtin_amdgcn_sqrtf(m128r * m128r + m128i * m128i);
+            float4 csq[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) csq[j] = ((const float4 *)(s_split + l * kSplitStride))[j];
 #pragma unroll
             for (int pp = 0; pp < 8; ++pp) {
                 const float zr = row_partner(bsh[7 - pp].x);
                 const float zi = row_partner(bsh[7 - pp].y);
-                const float2 cs = lds_read_b64(s_split + l + 16 * pp);
+                const float2 cs = (pp & 1) ? make_float2(csq[pp >> 1].z, csq[pp >> 1].w) : make_float2(csq[pp >> 1].x, csq[pp >> 1].y);
                 const float sr = a[pp].x + zr, si = a[pp].y - zi;
                 const float dr = a[pp].x - zr, di = a[pp].y + zi;
                 const float tr = cs.x * dr - cs.y * di;
@@ -912,6 +945,14 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
                     }
                     wave_sync();
                     const float *arow = s_wave + (l >> 2) * (kSlot + 8) + kMelOff + slot; // A[row l][k = slot] of K step 0
+                    float dctb[12];
+                    {
+                        const float4 *bq = (const float4 *)(s_dct + lane * kDctRow);
+                        const float4 b0 = bq[0], b1 = bq[1], b2 = bq[2];
+                        dctb[0] = b0.x, dctb[1] = b0.y, dctb[2] = b0.z, dctb[3] = b0.w;
+                        dctb[4] = b1.x, dctb[5] = b1.y, dctb[6] = b1.z, dctb[7] = b1.w;
+                        dctb[8] = b2.x, dctb[9] = b2.y, dctb[10] = b2.z, dctb[11] = b2.w;
+                    }
                     f32x4 dacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < kDctSteps; ++j)
@@ -1638,10 +1679,10 @@ int num_cus()
 
 size_t front512_lds_bytes(const FrontParams &p)
 {
-    size_t f = 512 + 512 + 2 * 264;                      // window pairs, pass twiddles, split twiddles
+    size_t f = 2 * 16 * kTabStride + 16 * kSplitStride;  // window pairs, pass twiddles, split twiddles
     f += (size_t)16 * p.mel_row_stride;                  // per-lane mel weights
     f += (size_t)32 * p.mel_rounds;                      // per-lane bin starts + filter ids
-    f += (p.dct && p.dct_mode != 1) ? (size_t)p.cols * p.dct_stride : 0; // transposed DCT table (dct_mode 0)
+    f += !p.dct ? 0 : p.dct_mode == 1 ? (size_t)64 * kDctRow : (size_t)p.cols * p.dct_stride; // DCT table (either form)
     f += kWaves * 4 * kSlot;                             // 4 frame slots per wave
     f += 4;                                              // block-local work counter
     return f * sizeof(float);

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1; LIB=$2; CNT=$3
 cd /tmp && export TMPDIR=/tmp
 rm -rf "$R/gpurun_out/$TAG"
-MFX_LIB=$LIB timeout -k 10 300 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$R/gpurun_out/$TAG" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/$TAG.log" 2>&1
+MFX_LIB=$LIB timeout -k 10 300 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$R/gpurun_out/$TAG" -- python3 "$R/bench.py" --steps 5 --warmup 1 --settle-ms 0 --no-cpu-baseline > "$R/gpurun_out/$TAG.log" 2>&1
 python3 - "$R/gpurun_out/$TAG" "$TAG" <<'PY'
 import csv, glob, sys, collections
 agg = collections.defaultdict(list)

@@ -10,11 +10,12 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_UNALIGNED_STALL SQ_BUSY_CYCLES" \
+           "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_CYCLES_VMEM SQ_INSTS_SMEM" \
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/p$i" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline "$@" > "$OUT/p$i.log" 2>&1 || echo "pass $i failed"
+  timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/p$i" -- python3 "$R/bench.py" --steps 5 --warmup 1 --settle-ms 0 --no-cpu-baseline "$@" > "$OUT/p$i.log" 2>&1 || echo "pass $i failed"
 done
-python3 - "$OUT" <<'PY'
+python3 - "$OUT" "$@" <<'PY'
 import csv, glob, sys, collections, json
 out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -22,7 +23,7 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
         if "mfx::" not in k: continue
-        short = "k_front512" if "k_front512" in k else "k_delta" if "k_delta" in k else k[:40]
+        short = next((n for n in ("k_front512", "k_front_reg", "k_front_wave", "k_delta16", "k_delta", "k_melcep", "k_norm") if n in k), k[:40])
         agg[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 json.dump(res, open(out + "/pmc_summary.json", "w"), indent=1, sort_keys=True)
@@ -30,9 +31,13 @@ json.dump(res, open(out + "/pmc_summary.json", "w"), indent=1, sort_keys=True)
 # FETCH_SIZE reports half of the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM;
 # confirmed for this kernel's 4-byte-per-lane loads by tools/ubench/fetch_calib.hip: 1 GiB read ->
 # 524 299 KiB), WRITE_SIZE is exact at 32-byte sector granularity (same calibration).
-k = res.get("k_front512") or {}
+wl = "C2"
+for i, a in enumerate(sys.argv):
+    if a == "--workload" and i + 1 < len(sys.argv): wl = sys.argv[i + 1]
+kn = next((n for n in ("k_front512", "k_front_reg", "k_front_wave") if n in res), "k_front512")
+k = res.get(kn) or {}
 if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
-    traffic = {"kernel": "k_front512", "workload": "C2",
+    traffic = {"kernel": kn, "workload": wl,
                "fetch_size_kib_raw": k["FETCH_SIZE"], "write_size_kib": k["WRITE_SIZE"],
                "hbm_read_bytes_per_launch": 2 * 1024 * k["FETCH_SIZE"], "hbm_write_bytes_per_launch": 1024 * k["WRITE_SIZE"],
                "hbm_bytes_per_launch": 2 * 1024 * k["FETCH_SIZE"] + 1024 * k["WRITE_SIZE"],
