@@ -249,6 +249,15 @@ constexpr int kDctSteps = 10;  // num_banks <= 40
 constexpr int kDctRow = 12;    // dwords per lane row of the B operand table in LDS (16-byte words, disjoint bank quads)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Partner fetch of the real split: lanes l >= 1 get x[16 - l] (mirror, then shift right by one inside the row);
+// lane 0, which the shift leaves without a source, keeps `own` -- its partner lives in its own registers.
+__device__ __forceinline__ float row_partner_own0(float own, float x)
+{
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, true);   // row_mirror
+    t = __builtin_amdgcn_update_dpp(__float_as_int(own), t, 0x111, 0xf, 0xf, false);    // row_shr:1, lane 0 keeps old
+    return __int_as_float(t);
+}
+
 template <bool ALIGNED, int NM>
 struct PcmRegs {
     uint32_t d[ALIGNED ? NM : 2 * NM];
@@ -560,7 +569,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
     float *s_melw = s_split + 16 * kSplitStride;     // [16][RS]
     int *s_mstart = (int *)(s_melw + 16 * RS);       // [rounds][16]
     int *s_mfid = s_mstart + 16 * rounds;            // [rounds][16]
-    float *s_dct = (float *)(s_mfid + 16 * rounds);  // [cols][DS]
+    int *s_mplan = s_mfid + 16 * rounds;             // [16][4] per-lane plan of the unrolled mel walk (dct_mode 1)
+    float *s_dct = (float *)(s_mplan + 64);          // [cols][DS]
     // dct_mode 0: transposed matrix [cols][DS]; dct_mode 1: matrix-pipe B operands per lane, [64][kDctRow]
     const int dct_floats = !p.dct ? 0 : p.dct_mode == 1 ? 64 * kDctRow : cols * DS;
     float *s_wave = s_dct + dct_floats + wave * (4 * kSlot);
@@ -587,6 +597,19 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
             s_mstart[i] = p.mel_lane_start[i];
             s_mfid[i] = p.mel_lane_fid[i];
         }
+        if (p.dct_mode == 1 && tid < 16) {
+            // plan of the unrolled mel walk: byte offset of round 0's first bin, the steps of that offset where the
+            // walk changes round (a trip t reads at offset + 32 t), and the three filter ids (idle: a word nobody reads)
+            auto st = [&](int r) { return r < rounds ? p.mel_lane_start[r * 16 + tid] : 0; };
+            auto fx = [&](int r) {
+                const int f = r < rounds ? p.mel_lane_fid[r * 16 + tid] : -1;
+                return f >= 0 ? f : 4 * kDctSteps;
+            };
+            s_mplan[4 * tid + 0] = 4 * st(0);
+            s_mplan[4 * tid + 1] = 4 * (st(1) - st(0)) - 4 * p.mel_L[0];
+            s_mplan[4 * tid + 2] = 4 * (st(2) - st(1)) - 4 * p.mel_L[1];
+            s_mplan[4 * tid + 3] = fx(0) | (fx(1) << 8) | (fx(2) << 16);
+        }
         if (p.dct_mode == 1) {
             // B operand of K step j on lane (k = lane >> 4, n = lane & 15) is dct[4 j + k][n]; zeros beyond the matrix
             for (int i = tid; i < 64 * kDctRow; i += kThreads) {
@@ -600,6 +623,10 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
     // the slots are read (times zero weights) before every word has been written once: make them finite
     for (int i = lane; i < 4 * kSlot; i += 64) s_wave[i] = 0.f;
     __syncthreads();
+    // Unrolled mel walk (dct_mode 1): at most 3 rounds and 8 trips of 8 bins in all.  mE* = trip at which a round ends.
+    const int mE0 = rounds > 0 ? p.mel_L[0] >> 3 : 0, mE1 = mE0 + (rounds > 1 ? p.mel_L[1] >> 3 : 0),
+              mE2 = mE1 + (rounds > 2 ? p.mel_L[2] >> 3 : 0);
+    const bool mel_fast = !TO_SPEC && p.dct_mode == 1 && rounds >= 1 && rounds <= 3 && mE2 <= 8;
 
     // ---- FUSE: the delta wave.  It consumes the block's tiles in order; a tile is ready once the
     // chunks it reads (its own rows and up to D rows either side) have their bits set in s_done.  The
@@ -827,9 +854,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
             // ---- real split + magnitude, one partner fetch per bin PAIR (k, 256 - k), k = l + 16 p, p < 8:
             //   S = Z[k] + conj Z[256-k], T = (-i W_512^k)(Z[k] - conj Z[256-k]):  X[k] = S + T,  X[256-k] = conj(S - T)
             // (the twiddle of bin 256 - k is the conjugate of bin k's).  The partner Z[256 - k] is register 15 - p of
-            // lane (16 - l) % 16; lane 0 pairs with itself one register further (bin 16 p <-> bin 16 (16 - p)), so the
-            // partner registers are taken from a copy that lane 0 holds shifted by one: the exchange itself is then
-            // the same two DPP moves on every lane.  Lane l ends with its own bins p < 8 and the bins of lane
+            // lane (16 - l) % 16; lane 0 pairs with itself one register further (bin 16 p <-> bin 16 (16 - p)): the
+            // second DPP move of the exchange (row_shr:1) has no source for lane 0 and leaves it that register.  Lane l ends with its own bins p < 8 and the bins of lane
             // (16 - l) % 16 for p >= 8 -- both go straight to their places (LDS or HBM), no second exchange.
             // Lane 0, p = 0 pairs bin 0 with the Nyquist bin 256 = Z[0] again: X[256] = Re Z[0] - Im Z[0] falls out
             // of the same formula; its self-paired bin 128 = conj-scaled Z[128] is done on the side.
@@ -842,12 +868,6 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
             }
             const float mag128 = 0.f;
 #else
-            float2 bsh[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                bsh[j].x = l == 0 ? a[(9 + j) & 15].x : a[8 + j].x;
-                bsh[j].y = l == 0 ? a[(9 + j) & 15].y : a[8 + j].y;
-            }
             const float m128r = a[8].x + a[8].x, m128i = a[8].y + a[8].y;
             const float mag128 = __builtin_amdgcn_sqrtf(m128r * m128r + m128i * m128i);
             float4 csq[4];
@@ -855,8 +875,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
             for (int j = 0; j < 4; ++j) csq[j] = ((const float4 *)(s_split + l * kSplitStride))[j];
 #pragma unroll
             for (int pp = 0; pp < 8; ++pp) {
-                const float zr = row_partner(bsh[7 - pp].x);
-                const float zi = row_partner(bsh[7 - pp].y);
+                const float zr = row_partner_own0(a[(16 - pp) & 15].x, a[15 - pp].x);
+                const float zi = row_partner_own0(a[(16 - pp) & 15].y, a[15 - pp].y);
                 const float2 cs = (pp & 1) ? make_float2(csq[pp >> 1].z, csq[pp >> 1].w) : make_float2(csq[pp >> 1].x, csq[pp >> 1].y);
                 const float sr = a[pp].x + zr, si = a[pp].y - zi;
                 const float dr = a[pp].x - zr, di = a[pp].y + zi;
@@ -902,6 +922,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
                     for (int pp = 0; pp < 8; ++pp) mhi[16 * pp] = mag_p[7 - pp];
                     if (l == 0) mg0[128] = mag128;
                 }
+                int4 mplan = make_int4(0, 0, 0, 0);
+                if (p.dct_mode == 1) mplan = *(const int4 *)(s_mplan + 4 * l);
                 wave_sync();
 
                 // ---- mel filterbank: per round every lane walks one filter's bins in ascending
@@ -920,6 +942,58 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
                     // copies: all 64 lanes read valid energies), so register 0 of the result is out[slot][c] on
                     // lane (slot, c) -- exactly the lane that stores it.
                     float *lm = xb + kMelOff + 8 * slot;
+                    if (mel_fast) {
+                        // the walk, fully unrolled and software pipelined: trip t + 1's six LDS reads are in flight during
+                        // trip t's eight multiply-adds; a round's end is a scalar branch (log, store, restart the sum)
+                        struct Trip {
+                            float4 w0, w1;
+                            float2 m[4];
+                        };
+                        const char *wb = (const char *)wrow;
+                        int mo = mplan.x;
+                        // (the round ends are re-read here so that the comparisons below are made where they are used:
+                        // hoisted out of the chunk loop they cost more scalar registers than there are)
+                        int e0 = mE0, e1 = mE1, e2 = mE2;
+                        asm volatile("" : "+s"(e0), "+s"(e1), "+s"(e2));
+                        auto issue = [&](Trip &T, int t) {
+                            const float4 *wp = (const float4 *)(wb + 32 * t);
+                            const float2 *mp = (const float2 *)((const char *)mg0 + mo + 32 * t);
+                            T.w0 = lds_read_b128(wp);
+                            T.w1 = lds_read_b128(wp + 1);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) T.m[q] = lds_read_b64(mp + q);
+                        };
+                        Trip tA, tB;
+                        float acc = 0.f;
+                        issue(tA, 0);
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            if (t < e2) {
+                                Trip &cur = (t & 1) ? tB : tA;
+                                Trip &nxt = (t & 1) ? tA : tB;
+                                if (t + 1 < e2) {
+                                    if (t + 1 == e0)
+                                        mo += mplan.y;
+                                    else if (t + 1 == e1)
+                                        mo += mplan.z;
+                                    issue(nxt, t + 1);
+                                }
+                                acc += cur.w0.x * cur.m[0].x;
+                                acc += cur.w0.y * cur.m[0].y;
+                                acc += cur.w0.z * cur.m[1].x;
+                                acc += cur.w0.w * cur.m[1].y;
+                                acc += cur.w1.x * cur.m[2].x;
+                                acc += cur.w1.y * cur.m[2].y;
+                                acc += cur.w1.z * cur.m[3].x;
+                                acc += cur.w1.w * cur.m[3].y;
+                                if (t + 1 == e0 || t + 1 == e1 || t + 1 == e2) {
+                                    const int fid = t + 1 == e0 ? (mplan.w & 255) : t + 1 == e1 ? ((mplan.w >> 8) & 255) : (mplan.w >> 16);
+                                    lm[fid] = MFX_LOG(fmaxf(acc, 1e-30f));
+                                    acc = 0.f;
+                                }
+                            }
+                        }
+                    } else
                     for (int r = 0; r < rounds; ++r) {
                         const int L = p.mel_L[r];
                         const float *mg = mg0 + s_mstart[r * 16 + l];
@@ -945,14 +1019,9 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
                     }
                     wave_sync();
                     const float *arow = s_wave + (l >> 2) * (kSlot + 8) + kMelOff + slot; // A[row l][k = slot] of K step 0
-                    float dctb[12];
-                    {
-                        const float4 *bq = (const float4 *)(s_dct + lane * kDctRow);
-                        const float4 b0 = bq[0], b1 = bq[1], b2 = bq[2];
-                        dctb[0] = b0.x, dctb[1] = b0.y, dctb[2] = b0.z, dctb[3] = b0.w;
-                        dctb[4] = b1.x, dctb[5] = b1.y, dctb[6] = b1.z, dctb[7] = b1.w;
-                        dctb[8] = b2.x, dctb[9] = b2.y, dctb[10] = b2.z, dctb[11] = b2.w;
-                    }
+                    const float4 *bq = (const float4 *)(s_dct + lane * kDctRow);
+                    const float4 dq0 = bq[0], dq1 = bq[1], dq2 = bq[2];
+                    const float dctb[12] = {dq0.x, dq0.y, dq0.z, dq0.w, dq1.x, dq1.y, dq1.z, dq1.w, dq2.x, dq2.y, dq2.z, dq2.w};
                     f32x4 dacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < kDctSteps; ++j)
@@ -1681,7 +1750,7 @@ size_t front512_lds_bytes(const FrontParams &p)
 {
     size_t f = 2 * 16 * kTabStride + 16 * kSplitStride;  // window pairs, pass twiddles, split twiddles
     f += (size_t)16 * p.mel_row_stride;                  // per-lane mel weights
-    f += (size_t)32 * p.mel_rounds;                      // per-lane bin starts + filter ids
+    f += (size_t)32 * p.mel_rounds + 64;                 // per-lane bin starts + filter ids, plan of the unrolled walk
     f += !p.dct ? 0 : p.dct_mode == 1 ? (size_t)64 * kDctRow : (size_t)p.cols * p.dct_stride; // DCT table (either form)
     f += kWaves * 4 * kSlot;                             // 4 frame slots per wave
     f += 4;                                              // block-local work counter
