@@ -1022,11 +1022,15 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
                     const float4 *bq = (const float4 *)(s_dct + lane * kDctRow);
                     const float4 dq0 = bq[0], dq1 = bq[1], dq2 = bq[2];
                     const float dctb[12] = {dq0.x, dq0.y, dq0.z, dq0.w, dq1.x, dq1.y, dq1.z, dq1.w, dq2.x, dq2.y, dq2.z, dq2.w};
-                    f32x4 dacc = {0.f, 0.f, 0.f, 0.f};
+                    // two accumulator chains (even and odd K steps): the 40-cycle dependent latency of the instruction is
+                    // covered by the other chain; each chain is an fmaf chain in ascending m, the two are added at the end
+                    f32x4 dacc = {0.f, 0.f, 0.f, 0.f}, dacc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int j = 0; j < kDctSteps; ++j)
+                    for (int j = 0; j < kDctSteps; j += 2) {
                         dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * j], dctb[j], dacc, 0, 0, 0);
-                    const float outv = dacc[0];
+                        dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * j + 4], dctb[j + 1], dacc2, 0, 0, 0);
+                    }
+                    const float outv = dacc[0] + dacc2[0];
                     // pitch 16 = compact static scratch: write whole 64-byte rows (zeros beyond cols)
                     if (live && (l < cols || p.feat_pitch == 16)) dst[l] = outv;
                 } else {
