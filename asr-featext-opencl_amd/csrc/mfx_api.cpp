@@ -651,7 +651,8 @@ extern "C" const char *mfx_dominant_kernel_name(const mfx_handle *h)
 
 extern "C" int mfx_set_window(mfx_handle *h, const float *window)
 {
-    if (!h || !window) return MFX_ERR_ARG;
+    if (!h) return MFX_ERR_ARG;
+    if (!window) return fail(h, MFX_ERR_ARG, "invalid argument");
     HIP_TRY(h, hipSetDevice(h->device));
     std::vector<float> padded((size_t)h->W2, 0.f);
     std::memcpy(padded.data(), window, sizeof(float) * h->W);
@@ -715,7 +716,8 @@ int carry_tail(mfx_handle *h, int total_samples)
 
 extern "C" int mfx_set_input(mfx_handle *h, const int16_t *pcm, int32_t samples, int32_t *frames_out)
 {
-    if (!h || !pcm || !frames_out || samples < 0) return MFX_ERR_ARG;
+    if (!h) return MFX_ERR_ARG;
+    if (!pcm || !frames_out || samples < 0) return fail(h, MFX_ERR_ARG, "invalid argument");
     *frames_out = 0;
     if (!h->have_window) return fail(h, MFX_ERR_STATE, "set_window has not been called");
     if (samples > h->input_buffer_size) return fail(h, MFX_ERR_BUFFER_TOO_SMALL, kMsgBuffer);
@@ -771,7 +773,8 @@ extern "C" int mfx_set_input(mfx_handle *h, const int16_t *pcm, int32_t samples,
 
 extern "C" int mfx_flush(mfx_handle *h, int32_t *frames_out)
 {
-    if (!h || !frames_out) return MFX_ERR_ARG;
+    if (!h) return MFX_ERR_ARG;
+    if (!frames_out) return fail(h, MFX_ERR_ARG, "invalid argument");
     *frames_out = 0;
     if (h->last_block) return MFX_OK; // nothing to flush (mfcccpu.cpp:350-351)
     HIP_TRY(h, hipSetDevice(h->device));
@@ -998,7 +1001,8 @@ extern "C" int mfx_apply(mfx_handle *h)
 
 extern "C" int mfx_apply_alphas(mfx_handle *h, const float *alphas, int32_t n_alpha)
 {
-    if (!h || !alphas || n_alpha < 1 || n_alpha > 4096) return MFX_ERR_ARG;
+    if (!h) return MFX_ERR_ARG;
+    if (!alphas || n_alpha < 1 || n_alpha > 4096) return fail(h, MFX_ERR_ARG, "invalid argument");
     for (int a = 0; a < n_alpha; ++a)
         if (!(alphas[a] > 0.f)) return fail(h, MFX_ERR_ARG, "alpha must be positive");
     return apply_impl(h, alphas, n_alpha);
@@ -1006,7 +1010,8 @@ extern "C" int mfx_apply_alphas(mfx_handle *h, const float *alphas, int32_t n_al
 
 extern "C" int mfx_get_output_data_alpha(mfx_handle *h, int32_t alpha_index, float *data_out, int32_t frames)
 {
-    if (!h || (!data_out && frames > 0) || frames < 0) return MFX_ERR_ARG;
+    if (!h) return MFX_ERR_ARG;
+    if ((!data_out && frames > 0) || frames < 0) return fail(h, MFX_ERR_ARG, "invalid argument");
     if (alpha_index < 0 || alpha_index >= h->sweep_n) return fail(h, MFX_ERR_ARG, "alpha index outside the last sweep");
     if (frames > h->cap_rows) return fail(h, MFX_ERR_WINDOW_HIGH, kMsgHigh);
     if (frames == 0) return MFX_OK;
@@ -1019,7 +1024,8 @@ extern "C" int mfx_get_output_data_alpha(mfx_handle *h, int32_t alpha_index, flo
 
 extern "C" int mfx_get_output_data(mfx_handle *h, float *data_out, int32_t frames)
 {
-    if (!h || (!data_out && frames > 0) || frames < 0) return MFX_ERR_ARG;
+    if (!h) return MFX_ERR_ARG;
+    if ((!data_out && frames > 0) || frames < 0) return fail(h, MFX_ERR_ARG, "invalid argument");
     if (frames > h->cap_rows) return fail(h, MFX_ERR_WINDOW_HIGH, kMsgHigh);
     if (frames == 0) return MFX_OK;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1184,7 +1190,8 @@ int plan_fused_delta(mfx_handle *h, const std::vector<int64_t> &T_of)
 extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offsets, const int64_t *lengths,
                               int64_t *out_rows, int64_t *total_rows)
 {
-    if (!h || n_utt < 0 || (n_utt > 0 && (!offsets || !lengths))) return MFX_ERR_ARG;
+    if (!h) return MFX_ERR_ARG;
+    if (n_utt < 0 || (n_utt > 0 && (!offsets || !lengths))) return fail(h, MFX_ERR_ARG, "invalid argument");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->n_utt = n_utt;
@@ -1275,7 +1282,8 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
 
 extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_total, float *d_out)
 {
-    if (!h || !d_pcm || !d_out || pcm_samples_total <= 0) return MFX_ERR_ARG;
+    if (!h) return MFX_ERR_ARG;
+    if (!d_pcm || !d_out || pcm_samples_total <= 0) return fail(h, MFX_ERR_ARG, "invalid argument");
     if (!h->have_window) return fail(h, MFX_ERR_STATE, "set_window has not been called");
     if (h->total_rows == 0) return MFX_OK;
     if (((uintptr_t)d_pcm & 3) != 0) return fail(h, MFX_ERR_ARG, "d_pcm must be 4-byte aligned");
@@ -1470,7 +1478,8 @@ extern "C" int mfx_batch_overlap(mfx_handle *h, int enable)
 
 extern "C" int mfx_batch_run_host(mfx_handle *h, const int16_t *pcm, int64_t pcm_samples_total, float *out)
 {
-    if (!h || !pcm || !out || pcm_samples_total <= 0) return MFX_ERR_ARG;
+    if (!h) return MFX_ERR_ARG;
+    if (!pcm || !out || pcm_samples_total <= 0) return fail(h, MFX_ERR_ARG, "invalid argument");
     HIP_TRY(h, hipSetDevice(h->device));
     // device-side staging of the host buffers, kept by the handle and grown on demand
     const size_t n_in = (size_t)pcm_samples_total * h->channels;
@@ -1496,7 +1505,8 @@ extern "C" int mfx_batch_run_host(mfx_handle *h, const int16_t *pcm, int64_t pcm
 
 extern "C" int64_t mfx_debug_read(mfx_handle *h, int kind, void *dst, int64_t dst_bytes)
 {
-    if (!h || !dst) return MFX_ERR_ARG;
+    if (!h) return MFX_ERR_ARG;
+    if (!dst) return fail(h, MFX_ERR_ARG, "invalid argument");
     if (hipSetDevice(h->device) != hipSuccess) return MFX_ERR_DEVICE;
     const void *src = nullptr;
     int64_t count = 0, esz = 4;

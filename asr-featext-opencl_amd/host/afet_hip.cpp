@@ -48,7 +48,9 @@ uint16_t rd16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 // "key -type value" lines up to "end_head"; 16-bit PCM, sample_byte_format 01 = little endian, 10 = big.
 Wav read_sphere(const std::vector<unsigned char> &b, const std::string &path)
 {
-    const size_t hdr = (size_t)std::atol(reinterpret_cast<const char *>(b.data()) + 8);
+    // "NIST_1A\n" then the header length as text on a line of its own: parse a bounded, terminated copy
+    const std::string len_field(reinterpret_cast<const char *>(b.data()) + 8, std::min<size_t>(b.size() - 8, 8));
+    const size_t hdr = (size_t)std::max(0L, std::atol(len_field.c_str()));
     if (hdr < 16 || hdr > b.size()) throw std::runtime_error("bad SPHERE header in \"" + path + "\"");
     const std::string text(reinterpret_cast<const char *>(b.data()), hdr);
     auto field = [&](const char *key, const std::string &dflt) -> std::string {
@@ -93,8 +95,9 @@ Wav read_wav(const std::string &path)
     bool have_fmt = false;
     while (pos + 8 <= b.size()) {
         const uint32_t sz = rd32(&b[pos + 4]);
-        const unsigned char *body = &b[pos + 8];
+        const unsigned char *body = b.data() + pos + 8;
         if (std::memcmp(&b[pos], "fmt ", 4) == 0 && sz >= 16) {
+            if (pos + 8 + 16 > b.size()) throw std::runtime_error("truncated fmt chunk in \"" + path + "\"");
             if (rd16(body) != 1 || rd16(body + 14) != 16) throw std::runtime_error("only 16-bit PCM is supported");
             w.channels = rd16(body + 2);
             w.sample_rate = (int)rd32(body + 4);
@@ -102,9 +105,9 @@ Wav read_wav(const std::string &path)
         } else if (std::memcmp(&b[pos], "data", 4) == 0) {
             const size_t avail = std::min<size_t>(sz, b.size() - pos - 8);
             w.pcm.resize(avail / 2);
-            std::memcpy(w.pcm.data(), body, w.pcm.size() * 2);
+            if (!w.pcm.empty()) std::memcpy(w.pcm.data(), body, w.pcm.size() * 2);
         }
-        pos += 8 + sz + (sz & 1);
+        pos += (size_t)8 + sz + (sz & 1);
     }
     if (!have_fmt || w.pcm.empty()) throw std::runtime_error("Error while loading \"" + path + "\"");
     return w;
@@ -158,15 +161,25 @@ void process_file(MfccHip &param, const Options &o, const Wav &w, const std::str
 {
     if ((float)w.sample_rate != sample_rate)
         throw std::runtime_error("File \"" + in + "\" has incorrect sample rate");
-    // mono: first channel (the reference reads one short per frame into a mono-sized buffer)
+    // Multi-channel input: ONE policy across the product -- the downmix of the batch kernels (channels = 2 in the C
+    // ABI: mono = (L + R) >> 1 in integer arithmetic), applied here on the host because the streaming
+    // interface is mono like the reference's (which has no downmix at all: it reads `frames` shorts into a mono-sized
+    // buffer, ASR_OCL.cpp:229-231).  More than two channels: the first two.
     std::vector<int16_t> mono(w.pcm.size() / w.channels);
-    for (size_t i = 0; i < mono.size(); ++i) mono[i] = w.pcm[i * w.channels];
+    for (size_t i = 0; i < mono.size(); ++i)
+        mono[i] = w.channels >= 2 ? (int16_t)(((int)w.pcm[i * w.channels] + (int)w.pcm[i * w.channels + 1]) >> 1)
+                                  : w.pcm[i * w.channels];
 
     const int limit = param.get_input_buffer_size();
     const int width = param.get_output_data_width();
     const int rows_cap = std::max(param.estimated_window_count(limit), 0) + 64;
     std::vector<float> rows((size_t)rows_cap * width);
-    const long double dt = o.shift_ms / 1000.0L, t0 = 0.5L * o.window_ms / 1000.0L;
+    // Frame time column.  The reference divides its window / shift IN MILLISECONDS by the sample rate
+    // (ASR_OCL.cpp:225-226: cfg.shift / cfg.sample_rate, 0.5f * cfg.window_size / cfg.sample_rate, float arithmetic):
+    // 0.000625 s per frame at 10 ms / 16 kHz instead of 0.01 s.  --bug-compat 1 (default) prints
+    // what the reference prints, --bug-compat 0 the times in seconds.
+    const long double dt = o.bug_compat ? (long double)(o.shift_ms / sample_rate) : o.shift_ms / 1000.0L;
+    const long double t0 = o.bug_compat ? (long double)(0.5f * o.window_ms / sample_rate) : 0.5L * o.window_ms / 1000.0L;
 
     std::vector<std::pair<float, FILE *>> outs;
     int idx = 0;

@@ -13,6 +13,15 @@
 
 #include <stdexcept>
 
+// -DAFET_USE_REFERENCE_HEADERS: take ParamBase / MfccBase / Normalizer from the reference's OWN headers
+// (parambase.h:6-33, mfccbase.h:6-52, normalizer.h:5; add -I<reference>) and link the reference's parambase.cpp /
+// mfccbase.cpp -- this is how MfccHip drops into the reference tree itself (INTEGRATION.md section 1;
+// tests/test_host.py::test_mfcchip_builds_against_reference_headers).  Without it the mirror below stands in.
+#ifdef AFET_USE_REFERENCE_HEADERS
+#include "mfccbase.h"
+struct mfx_handle;
+#else
+
 struct mfx_handle;
 
 namespace Normalizer {
@@ -34,7 +43,7 @@ public:
     int get_input_buffer_size() const { return m_input_buffer_size; }
     // floor(float(samples - (W - S)) / S), float32 arithmetic as the reference (parambase.cpp:16-19)
     int estimated_window_count(int samples) const;
-    virtual void set_alpha(float alpha) { m_alpha = alpha; }
+    void set_alpha(float alpha) { m_alpha = alpha; }   // not virtual (parambase.h:25): apply() forwards m_alpha
 
     virtual void set_window(const float *window) = 0;
     virtual int set_input(const short *data, int samples) = 0;
@@ -67,6 +76,8 @@ protected:
     bool m_want_c0, m_norm_after_dyn;
 };
 
+#endif // AFET_USE_REFERENCE_HEADERS
+
 // The MI355X back end.  `hip_device` takes the place of MfccOpenCL's trailing cl_device_id
 // (mfccopencl.h:60).  Errors surface as std::runtime_error with the reference's messages.
 class MfccHip : public MfccBase {
@@ -79,7 +90,7 @@ public:
     MfccHip(const MfccHip &) = delete;
     MfccHip &operator=(const MfccHip &) = delete;
 
-    void set_alpha(float alpha) override;
+    // set_alpha is ParamBase's own (non-virtual, stores m_alpha): apply() hands m_alpha to the library
     void set_window(const float *window) override;
     int set_input(const short *data, int samples) override;
     int flush() override;

@@ -5,7 +5,9 @@
 #include "../../include/mfx.h"
 #include "afet_param.h"
 
-// ---- ParamBase / MfccBase bookkeeping (parambase.cpp:4-19, mfccbase.cpp:3-43) ----
+// ---- ParamBase / MfccBase bookkeeping (parambase.cpp:4-19, mfccbase.cpp:3-43); with the reference's own headers
+// the reference's own parambase.cpp / mfccbase.cpp are linked instead ----
+#ifndef AFET_USE_REFERENCE_HEADERS
 
 ParamBase::ParamBase(int input_buffer_size, int window_size, int shift, Normalizer::norm_t norm, dyn_t dyn)
     : m_window_size(window_size), m_shift(shift), m_alpha(1), m_norm(norm), m_dyn(dyn), m_last_block(false)
@@ -43,6 +45,8 @@ int MfccBase::get_output_data_width() const
     return m_dyn == DYN_ACC ? 3 * cols : m_dyn == DYN_DELTA ? 2 * cols : cols;
 }
 
+#endif // AFET_USE_REFERENCE_HEADERS
+
 // ---- MfccHip ----
 
 MfccHip::MfccHip(int input_buffer_size, int window_size, int shift, int num_banks, float sample_rate,
@@ -78,13 +82,11 @@ MfccHip::~MfccHip() { mfx_destroy(m_handle); }
 
 void MfccHip::check(int status) const
 {
-    if (status != MFX_OK) throw std::runtime_error(mfx_last_error(m_handle));
-}
-
-void MfccHip::set_alpha(float alpha)
-{
-    m_alpha = alpha;
-    check(mfx_set_alpha(m_handle, alpha));
+    if (status == MFX_OK) return;
+    // the library's message for this call when it left one (the reference's fixed strings among them), else the
+    // generic text of the status code
+    const char *m = mfx_last_error(m_handle);
+    throw std::runtime_error((m && *m) ? m : mfx_status_string(status));
 }
 
 void MfccHip::set_window(const float *window) { check(mfx_set_window(m_handle, window)); }
@@ -105,7 +107,13 @@ int MfccHip::flush()
     return frames;
 }
 
-void MfccHip::apply() { check(mfx_apply(m_handle)); }
+void MfccHip::apply()
+{
+    // the caller's set_alpha (ParamBase's, not virtual) only stored m_alpha: it takes effect here, as in the
+    // reference, whose apply() rebuilds the filterbank from m_alpha every time (mfcccpu.cpp:194)
+    check(mfx_set_alpha(m_handle, m_alpha));
+    check(mfx_apply(m_handle));
+}
 
 void MfccHip::get_output_data(float *data_out, int window_count)
 {

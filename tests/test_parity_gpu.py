@@ -561,9 +561,17 @@ def test_cpp_driver_text_output(orc, a0001, tmp_path):
     got = np.array(rows, dtype=np.float64)
     assert got.shape == (711, 40)
     want = orc.run_utterance(orc.make_config(32000, num_banks=26, ceps_len=13), a0001)
-    # column 0 is the frame time: 0.5*window + t*shift (ASR_OCL.cpp:224-225,254)
-    np.testing.assert_allclose(got[:, 0], 0.0125 + 0.01 * np.arange(711), atol=1e-6)
+    # column 0 is the frame time as the reference prints it: (0.5f * window_ms + t * shift_ms) / sample_rate, its
+    # milliseconds divided by Hz (ASR_OCL.cpp:225-226,254) -- 0.00078125 + 0.000625 t at 25/10 ms, 16 kHz
+    np.testing.assert_allclose(got[:, 0], 0.00078125 + 0.000625 * np.arange(711), atol=1e-6)
     assert np.abs(got[:, 1:] - want).max() <= 1e-4 * np.abs(want).max() + 1e-6   # + %f quantisation
+    # --bug-compat 0: the same rows with the time column in seconds (0.5 * window + t * shift)
+    out0 = tmp_path / "a0001_s.txt"
+    subprocess.check_call([exe, "--bug-compat", "0", "--banks", "26", "--ceps", "13", "--c0", "0", "--norm", "0", "--dyn", "2",
+                           "--l1", "3", "--l2", "3", "--sample-limit", "32000", os.path.join(GOLDEN, "a0001.wav"), str(out0)])
+    got0 = np.array([[float(v) for v in line.strip().strip("|").split("|")] for line in open(out0)])
+    np.testing.assert_allclose(got0[:, 0], 0.0125 + 0.01 * np.arange(711), atol=1e-6)
+    assert np.array_equal(got0[:, 1:], got[:, 1:])
 
 
 def test_cpp_driver_sphere_input_and_htk_output(orc, tmp_path):
