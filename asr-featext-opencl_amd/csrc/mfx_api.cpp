@@ -112,6 +112,7 @@ struct mfx_handle {
     DevBuf<Chunk> d_chunks;
     DevBuf<Segment> d_segs;
     DevBuf<float> d_stats_batch, d_spec_slab, d_host_out;
+    DevBuf<double> d_norm_partial;       // chunk results of the normaliser's statistics (segments longer than 4096 rows)
     DevBuf<int16_t> d_host_pcm;          // mfx_batch_run_host: device copies of the caller's host buffers
     DevBuf<float> d_static16[2]; // compact [rows][16] statics between front end and delta (double buffered for overlap)
     // optional overlap of the delta/normalisation tail of batch i with the front end of batch i+1
@@ -283,10 +284,17 @@ int prof_collect(mfx_handle *h)
 
 // ---- normalisation helper: stats (unless reused) + apply over one column group
 int run_norm(mfx_handle *h, float *data, int pitch, int col0, const Segment *segs, int n_segs, const Segment *seg0,
-             int row_off, float *stats, bool use_last)
+             int row_off, float *stats, bool use_last, int max_rows)
 {
     NormParams np;
     std::memset(&np, 0, sizeof(np));
+    np.max_rows = max_rows;
+    const size_t need = norm_partial_doubles(seg0 ? 1 : n_segs, max_rows, h->cols);
+    if (need > h->d_norm_partial.n) { // (sized at create / plan time for the usual shapes: not reached in a timed loop)
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, h->d_norm_partial.alloc(need));
+    }
+    np.partial = h->d_norm_partial.p;
     np.data = data;
     np.pitch = pitch;
     np.col0 = col0;
@@ -366,6 +374,7 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_src.release();
     h->d_blk.release();
     h->d_stats_stream.release();
+    h->d_norm_partial.release();
     h->d_host_pcm.release();
     h->d_host_out.release();
     h->d_fchunks.release();
@@ -548,6 +557,10 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
     if (h->d_src.alloc((size_t)h->cap_rows * h->cols) != hipSuccess) return bail(MFX_ERR_DEVICE);
     if (h->d_blk.alloc((size_t)h->cap_rows * h->width) != hipSuccess) return bail(MFX_ERR_DEVICE);
     if (h->d_stats_stream.alloc((size_t)3 * 2 * h->cols) != hipSuccess) return bail(MFX_ERR_DEVICE);
+    if (cfg->norm != MFX_NORM_NONE) { // chunk results of the statistics over a long streaming block
+        const size_t need = norm_partial_doubles(1, h->cap_rows, h->cols);
+        if (need > 0 && h->d_norm_partial.alloc(need) != hipSuccess) return bail(MFX_ERR_DEVICE);
+    }
     if (hipMemset(h->d_stats_stream.p, 0, (size_t)3 * 2 * h->cols * sizeof(float)) != hipSuccess)
         return bail(MFX_ERR_DEVICE);
     {
@@ -958,7 +971,7 @@ int apply_impl(mfx_handle *h, const float *alphas, int n_alpha)
 
     const bool norm = h->cfg.norm != MFX_NORM_NONE;
     if (norm && !h->cfg.norm_after_dyn) { // normalise statics (with context) before the deltas
-        rc = run_norm(h, d_src, h->cols, 0, segs_ctx, n_tab, sweep ? nullptr : &sg, 0, d_stats, use_last);
+        rc = run_norm(h, d_src, h->cols, 0, segs_ctx, n_tab, sweep ? nullptr : &sg, 0, d_stats, use_last, wcnd);
         if (rc != MFX_OK) return rc;
     }
 
@@ -982,7 +995,7 @@ int apply_impl(mfx_handle *h, const float *alphas, int n_alpha)
         const int groups = h->width / h->cols;
         for (int g = 0; g < groups; ++g) {
             rc = run_norm(h, d_blk, h->width, g * h->cols, segs_out, n_tab, sweep ? nullptr : &sd, 0,
-                          d_stats + (size_t)g * n_tab * 2 * h->cols, use_last);
+                          d_stats + (size_t)g * n_tab * 2 * h->cols, use_last, wc);
             if (rc != MFX_OK) return rc;
         }
     }
@@ -1232,6 +1245,13 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
         s.lo = 0;
         s.hi = (int32_t)std::max<int64_t>(T - 1, 0);
         s.static_off = 0;
+        // Statistics of the normaliser (norm after dyn): the reference, fed the utterance as ONE block (its default
+        // sample_limit holds ~10 minutes of audio), computes them over the T - D rows that block delivers and
+        // re-uses them for the D rows of the flush (mfcccpu.cpp:377-388,395-407; normalizercpu.cpp:22-27).  That is
+        // the default here too (batch_norm_stats = 0); 1 = over all T rows.  Normalisation before the deltas covers
+        // the block's T rows with context in the reference as well, i.e. all rows either way.
+        s.pad = (h->cfg.norm != MFX_NORM_NONE && h->cfg.norm_after_dyn && h->cfg.batch_norm_stats == 0 && T > h->D)
+                    ? (int32_t)(T - h->D) : 0;
         tiles_max = std::max<int>(tiles_max, (int)((T + 63) / 64));
         row += T;
     }
@@ -1268,7 +1288,11 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
     if (total_rows) *total_rows = row;
     HIP_TRY(h, upload(h->d_chunks, h->h_chunks));
     HIP_TRY(h, upload(h->d_segs, segs));
-    if (h->cfg.norm != MFX_NORM_NONE) HIP_TRY(h, h->d_stats_batch.alloc((size_t)n_utt * 3 * 2 * h->cols));
+    if (h->cfg.norm != MFX_NORM_NONE) {
+        HIP_TRY(h, h->d_stats_batch.alloc((size_t)n_utt * 3 * 2 * h->cols));
+        const size_t need = norm_partial_doubles(n_utt, tiles_max * 64, h->cols);
+        if (need > h->d_norm_partial.n) HIP_TRY(h, h->d_norm_partial.alloc(need));
+    }
     {
         int rcf = plan_fused_delta(h, T_of);
         if (rcf != MFX_OK) return rcf;
@@ -1421,7 +1445,7 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
     } swap_guard(h, tail_stream);
     const bool norm = h->cfg.norm != MFX_NORM_NONE;
     if (norm && !h->cfg.norm_after_dyn) {
-        rc = run_norm(h, d_out, h->width, 0, h->d_segs.p, h->n_utt, nullptr, 0, h->d_stats_batch.p, false);
+        rc = run_norm(h, d_out, h->width, 0, h->d_segs.p, h->n_utt, nullptr, 0, h->d_stats_batch.p, false, h->tiles_max * 64);
         if (rc != MFX_OK) return rc;
     }
     if (h->l1 > 0 && !fuse) {
@@ -1443,7 +1467,7 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
         const int groups = h->width / h->cols;
         for (int g = 0; g < groups; ++g) {
             rc = run_norm(h, d_out, h->width, g * h->cols, h->d_segs.p, h->n_utt, nullptr, 0,
-                          h->d_stats_batch.p + (size_t)g * h->n_utt * 2 * h->cols, false);
+                          h->d_stats_batch.p + (size_t)g * h->n_utt * 2 * h->cols, false, h->tiles_max * 64);
             if (rc != MFX_OK) return rc;
         }
     }
@@ -1532,6 +1556,16 @@ extern "C" int64_t mfx_debug_read(mfx_handle *h, int kind, void *dst, int64_t ds
     case 4: // raw head of the spectrum buffer (dev builds park in-kernel stamps there)
         src = h->d_spec.p;
         count = std::min<int64_t>(dst_bytes / 4, (int64_t)h->d_spec.n);
+        break;
+    case 5: // normaliser statistics of the last streaming apply(): [groups][2][cols] = (mean, multiplier) per column
+            // group (static, delta, delta-delta when normalising after the deltas; statics only before)
+        src = h->d_stats_stream.p;
+        count = h->cfg.norm == MFX_NORM_NONE ? 0 : (int64_t)(h->cfg.norm_after_dyn ? h->width / h->cols : 1) * 2 * h->cols;
+        break;
+    case 6: // normaliser statistics of the last batch run: [groups][n_utt][2][cols]
+        src = h->d_stats_batch.p;
+        count = h->cfg.norm == MFX_NORM_NONE ? 0
+                                             : (int64_t)(h->cfg.norm_after_dyn ? h->width / h->cols : 1) * h->n_utt * 2 * h->cols;
         break;
     default:
         return MFX_ERR_ARG;

@@ -31,7 +31,7 @@ struct Segment {
     int32_t shift;      // padded[i] = src[clamp(i + shift, lo, hi)] (rows relative to src_row0)
     int32_t lo, hi;
     int32_t static_off; // static part of output row r is src row r + static_off
-    int32_t pad;
+    int32_t pad;        // normalisation: rows the statistics cover (0 = all n_out rows)
 };
 
 // One tile of the delta stage fused into the 512-point kernel: <= 64 consecutive output rows of one
@@ -155,6 +155,9 @@ struct NormParams {
     float *stats;          // [n_segs][2][cols]: mean, scale (persist across calls for use_last_stats)
     int32_t inline_seg;    // nonzero: ignore segs and use seg0
     Segment seg0;
+    int32_t max_rows;      // largest row count of any segment (sizes the grids)
+    int32_t chunks;        // set by the launcher: row chunks per segment
+    double *partial;       // [n_segs][chunks][4][cols] scratch, needed when max_rows > 4096 (norm_partial_doubles)
 };
 
 // All launchers are asynchronous on `stream` and return the launch status.
@@ -168,6 +171,8 @@ size_t front_wave_lds_bytes(const FrontParams &p, bool fused);
 hipError_t launch_melcep(const MelcepParams &p, hipStream_t stream);
 hipError_t launch_delta(const DeltaParams &p, hipStream_t stream);
 hipError_t launch_norm_stats(const NormParams &p, hipStream_t stream);
+// doubles of NormParams::partial for n_segs segments of at most max_rows rows (0: none needed)
+size_t norm_partial_doubles(int n_segs, int max_rows, int cols);
 hipError_t launch_norm_apply(const NormParams &p, hipStream_t stream);
 
 // dynamic LDS bytes one block of the 512-point kernel needs for these parameters

@@ -739,7 +739,10 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
         // buffer descriptor over [chunk start, end of PCM): out-of-range lanes read 0
         const int64_t base_s = ALIGNED ? pcm_off : (pcm_off & ~(int64_t)1);
         x.odd0 = ALIGNED ? 0 : (int)(pcm_off & 1);
-        int64_t bytes_left = valid ? (p.pcm_total - base_s) * 2 : 0;
+        // (rounded up to whole 32-bit words: with an odd sample count the array's last sample sits in a word whose
+        // upper half lies past the end, and the range check would drop the whole word -- the base is 4-byte aligned,
+        // so that word is inside the allocation, and the half past the end only ever meets a zero window tap)
+        int64_t bytes_left = valid ? (((p.pcm_total - base_s) * 2 + 3) & ~(int64_t)3) : 0;
         if (bytes_left > 0xfffffff0ll) bytes_left = 0xfffffff0ll;
         if (bytes_left < 0) bytes_left = 0;
         const uintptr_t bp = (uintptr_t)(p.pcm + base_s);
@@ -1670,52 +1673,104 @@ __global__ void __launch_bounds__(256, 7) k_delta16(DeltaParams p)
 // ------------------------------------------------------------------------------------------------
 // normalisation (normalizercpu.cpp:22-89): per segment, per column statistics in double.
 // stats layout [seg][2][cols]: mean, multiplier.
+//
+// k_norm_stats: one block per (row chunk, segment).  The block reads its rows as they lie in memory: a thread is
+// (row rr of the pass, column c), consecutive threads read consecutive floats of a row, a pass covers 256 / Cp
+// whole rows (Cp = columns rounded up to a power of two).  Sums in double as the reference's (sum2 takes the
+// float product v * v, normalizercpu.cpp:44); the partial results of the passes' rows are combined through LDS
+// in a fixed order.  A segment longer than kNormChunkRows rows is cut into chunks whose partial results go to
+// a scratch array and are combined, again in a fixed order, by k_norm_finalize -- results do not depend on timing.
+// Statistics cover the first `stat_rows` rows of the segment (Segment::pad; 0 = all n_out rows): the reference
+// computes them over the block it delivers and re-uses them for the flush rows (mfcccpu.cpp:377-388).
 // ------------------------------------------------------------------------------------------------
+constexpr int kNormChunkRows = 4096;
+
+__device__ __forceinline__ void norm_finish(const NormParams &p, int seg, int c, int n, double S, double S2, float mn, float mx)
+{
+    const float mean = (float)(S / n);
+    float mult = 1.f;
+    if (p.norm_type == 2)
+        mult = (float)sqrt((n - 1) / (S2 - S * (S / n)));
+    else if (p.norm_type == 3)
+        mult = 1.f / fmaxf(fabsf(mn - mean), fabsf(mx - mean));
+    float *st = p.stats + (int64_t)seg * 2 * p.cols;
+    st[c] = mean;
+    st[p.cols + c] = mult;
+}
+
 __global__ void __launch_bounds__(256) k_norm_stats(NormParams p)
 {
     __shared__ double s_sum[256], s_sum2[256];
     __shared__ float s_min[256], s_max[256];
     const Segment sg = p.inline_seg ? p.seg0 : p.segs[blockIdx.y];
-    const int c = blockIdx.x; // one block per (column, segment)
-    const int n = sg.n_out;
-    const float *base = p.data + (sg.out_row0 + p.row_off) * (int64_t)p.pitch + p.col0 + c;
+    const int n = sg.pad > 0 ? sg.pad : sg.n_out;
+    const int r0 = blockIdx.x * kNormChunkRows;
+    if (r0 >= n && blockIdx.x > 0) return;
+    const int r1 = min(n, r0 + kNormChunkRows);
+    int lg = 0;
+    while ((1 << lg) < p.cols) ++lg;
+    const int Cp = 1 << lg, rpp = 256 >> lg;          // columns per row of threads, rows per pass (cols <= 256)
+    const int tid = threadIdx.x, rr = tid >> lg, c = tid & (Cp - 1);
+    const float *base = p.data + (sg.out_row0 + p.row_off) * (int64_t)p.pitch + p.col0;
     double sum = 0, sum2 = 0;
     float mn = 3.402823466e+38f, mx = -3.402823466e+38f;
-    for (int r = threadIdx.x; r < n; r += 256) {
-        const float v = base[(int64_t)r * p.pitch];
-        sum += v;
-        sum2 += (double)(v * v);
-        mn = fminf(mn, v);
-        mx = fmaxf(mx, v);
-    }
-    s_sum[threadIdx.x] = sum;
-    s_sum2[threadIdx.x] = sum2;
-    s_min[threadIdx.x] = mn;
-    s_max[threadIdx.x] = mx;
+    if (c < p.cols)
+        for (int r = r0 + rr; r < r1; r += rpp) {
+            const float v = base[(int64_t)r * p.pitch + c];
+            sum += v;
+            sum2 += (double)(v * v);
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
+    s_sum[tid] = sum;
+    s_sum2[tid] = sum2;
+    s_min[tid] = mn;
+    s_max[tid] = mx;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            s_sum[threadIdx.x] += s_sum[threadIdx.x + s];
-            s_sum2[threadIdx.x] += s_sum2[threadIdx.x + s];
-            s_min[threadIdx.x] = fminf(s_min[threadIdx.x], s_min[threadIdx.x + s]);
-            s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + s]);
+    for (int s = rpp >> 1; s > 0; s >>= 1) {
+        if (rr < s) {
+            const int o = tid + (s << lg);
+            s_sum[tid] += s_sum[o];
+            s_sum2[tid] += s_sum2[o];
+            s_min[tid] = fminf(s_min[tid], s_min[o]);
+            s_max[tid] = fmaxf(s_max[tid], s_max[o]);
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const double S = s_sum[0], S2 = s_sum2[0];
-        const float mean = (float)(S / n);
-        float mult = 1.f;
-        if (p.norm_type == 2)
-            mult = (float)sqrt((n - 1) / (S2 - S * (S / n)));
-        else if (p.norm_type == 3)
-            mult = 1.f / fmaxf(fabsf(s_min[0] - mean), fabsf(s_max[0] - mean));
-        float *st = p.stats + (int64_t)blockIdx.y * 2 * p.cols;
-        st[c] = mean;
-        st[p.cols + c] = mult;
+    if (rr == 0 && c < p.cols) {
+        if (p.chunks <= 1) {
+            norm_finish(p, blockIdx.y, c, n, s_sum[tid], s_sum2[tid], s_min[tid], s_max[tid]);
+        } else {
+            double *q = p.partial + ((int64_t)blockIdx.y * p.chunks + blockIdx.x) * 4 * p.cols;
+            q[c] = s_sum[tid];
+            q[p.cols + c] = s_sum2[tid];
+            q[2 * p.cols + c] = (double)s_min[tid];
+            q[3 * p.cols + c] = (double)s_max[tid];
+        }
     }
 }
 
+// chunks > 1: combine the chunk results of a segment in ascending chunk order
+__global__ void __launch_bounds__(256) k_norm_finalize(NormParams p)
+{
+    const Segment sg = p.inline_seg ? p.seg0 : p.segs[blockIdx.x];
+    const int n = sg.pad > 0 ? sg.pad : sg.n_out;
+    const int used = (n + kNormChunkRows - 1) / kNormChunkRows;
+    for (int c = threadIdx.x; c < p.cols; c += 256) {
+        double S = 0, S2 = 0;
+        float mn = 3.402823466e+38f, mx = -3.402823466e+38f;
+        for (int k = 0; k < used; ++k) {
+            const double *q = p.partial + ((int64_t)blockIdx.x * p.chunks + k) * 4 * p.cols;
+            S += q[c];
+            S2 += q[p.cols + c];
+            mn = fminf(mn, (float)q[2 * p.cols + c]);
+            mx = fmaxf(mx, (float)q[3 * p.cols + c]);
+        }
+        norm_finish(p, blockIdx.x, c, n, S, S2, mn, mx);
+    }
+}
+
+// (x - mean) [* multiplier] in place over all n_out rows of the segment; grid.x is sized from the row count
 __global__ void __launch_bounds__(256) k_norm_apply(NormParams p)
 {
     const Segment sg = p.inline_seg ? p.seg0 : p.segs[blockIdx.y];
@@ -2011,28 +2066,46 @@ hipError_t launch_delta(const DeltaParams &p, hipStream_t stream)
     return hipGetLastError();
 }
 
+static int norm_chunks(int max_rows) { return max_rows <= kNormChunkRows ? 1 : (max_rows + kNormChunkRows - 1) / kNormChunkRows; }
+
 hipError_t launch_norm_stats(const NormParams &p, hipStream_t stream)
 {
     if (p.n_segs <= 0) return hipSuccess;
+    if (p.cols > 256) return hipErrorInvalidValue;
+    const int chunks = norm_chunks(p.max_rows);
+    if (chunks > 1 && !p.partial) return hipErrorInvalidValue;
     for (int s0 = 0; s0 < p.n_segs; s0 += 65535) {
         NormParams q = p;
         q.segs = p.segs + s0;
         q.stats = p.stats + (int64_t)s0 * 2 * p.cols;
         q.n_segs = (p.n_segs - s0) < 65535 ? (p.n_segs - s0) : 65535;
-        hipLaunchKernelGGL(k_norm_stats, dim3(p.cols, q.n_segs), dim3(256), 0, stream, q);
+        q.chunks = chunks;
+        if (chunks > 1) q.partial = p.partial + (int64_t)s0 * chunks * 4 * p.cols;
+        hipLaunchKernelGGL(k_norm_stats, dim3(chunks, q.n_segs), dim3(256), 0, stream, q);
+        if (chunks > 1) hipLaunchKernelGGL(k_norm_finalize, dim3(q.n_segs), dim3(256), 0, stream, q);
     }
     return hipGetLastError();
+}
+
+size_t norm_partial_doubles(int n_segs, int max_rows, int cols)
+{
+    const int ch = norm_chunks(max_rows);
+    return ch <= 1 ? 0 : (size_t)n_segs * ch * 4 * cols;
 }
 
 hipError_t launch_norm_apply(const NormParams &p, hipStream_t stream)
 {
     if (p.n_segs <= 0) return hipSuccess;
+    // about 2048 elements per block, whatever the row count (a streaming block is one long segment)
+    int64_t gx = ((int64_t)(p.max_rows > 0 ? p.max_rows : 1) * p.cols + 2047) / 2048;
+    if (gx < 1) gx = 1;
+    if (gx > 4096) gx = 4096;
     for (int s0 = 0; s0 < p.n_segs; s0 += 65535) {
         NormParams q = p;
         q.segs = p.segs + s0;
         q.stats = p.stats + (int64_t)s0 * 2 * p.cols;
         q.n_segs = (p.n_segs - s0) < 65535 ? (p.n_segs - s0) : 65535;
-        hipLaunchKernelGGL(k_norm_apply, dim3(8, q.n_segs), dim3(256), 0, stream, q);
+        hipLaunchKernelGGL(k_norm_apply, dim3((unsigned)gx, q.n_segs), dim3(256), 0, stream, q);
     }
     return hipGetLastError();
 }

@@ -70,7 +70,11 @@ typedef struct mfx_config {
     int32_t bug_compat;        /* 1 = reproduce reference behaviour B1 (static rows of a flush that
                                   follows exactly one set_input are read D rows early,
                                   mfcccpu.cpp:439 + segmentercpu.cpp:97-106); 0 = correct rows       */
-    int32_t reserved[5];
+    int32_t batch_norm_stats;  /* batch entries, norm after dyn: 0 = statistics as the reference computes them for
+                                  an utterance it consumes as one block -- over the T - D rows that block delivers,
+                                  re-used for the D flush rows (mfcccpu.cpp:377-388,395-407, normalizercpu.cpp:22-27);
+                                  1 = over all T rows of the utterance                                  */
+    int32_t reserved[4];
 } mfx_config;
 
 typedef struct mfx_handle mfx_handle;
@@ -142,7 +146,11 @@ int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offsets, const i
 
 /* Run the planned batch on DEVICE pointers: d_pcm (int16, HBM) -> d_out (float [total_rows][width],
  * HBM).  Asynchronous on the handle's stream; nothing is copied to or from the host.  This is the
- * entry the roofline numbers are measured on. */
+ * entry the roofline numbers are measured on.  d_pcm must be 4-byte aligned; when the number of int16
+ * elements is odd the kernels read the 32-bit word that holds the last sample whole (2 bytes past the
+ * last element, inside any device allocation; that half-word only meets a zero window tap).
+ * With normalisation on, an utterance's statistics are the reference's for a file consumed as one
+ * block (mfx_config.batch_norm_stats). */
 int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_total, float *d_out);
 
 /* Opt-in pipelining of consecutive batches: with enable=1 the delta / normalisation tail of a batch runs

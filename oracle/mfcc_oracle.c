@@ -748,6 +748,14 @@ int orc_get_output_data(orc_mfcc *o, float *data_out, int window_count)
     return ORC_OK;
 }
 
+/* persistent statistics of the three normaliser instances (mfcccpu.h:31-33: static, delta, delta-delta), as the last
+ * apply() left them: which = 0 the means, 1 the multipliers (normalizercpu.cpp m_var for CVN, m_minmax for MINMAX) */
+const float *orc_tap_norm_stats(const orc_mfcc *o, int group, int which)
+{
+    if (group < 0 || group > 2) return 0;
+    if (which == 0) return o->n_mean[group];
+    return o->cfg.norm == ORC_NORM_MINMAX ? o->n_minmax[group] : o->n_var[group];
+}
 const float *orc_tap_frames(const orc_mfcc *o) { return o->data; }
 const float *orc_tap_fft(const orc_mfcc *o) { return o->fft; }
 const float *orc_tap_mel(const orc_mfcc *o) { return o->mel; }

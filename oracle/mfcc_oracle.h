@@ -86,6 +86,9 @@ const float *orc_tap_mfcc(const orc_mfcc *o);     /* [window_limit][dct_len] or 
 const float *orc_tap_filters(const orc_mfcc *o);  /* [2][W2]                       */
 const int *orc_tap_filter_beg(const orc_mfcc *o); /* [num_banks+2]                 */
 const float *orc_tap_dct_matrix(const orc_mfcc *o); /* [num_banks][dct_len] or NULL */
+/* normaliser statistics after apply(): group 0/1/2 = static/delta/delta-delta instance, which 0 = mean, 1 = multiplier;
+ * cols floats each (normalizercpu.cpp:22-67) */
+const float *orc_tap_norm_stats(const orc_mfcc *o, int group, int which);
 
 /* ---- standalone stage functions (compared 1:1 with the real reference objects in oracle/_ref) ---- */
 

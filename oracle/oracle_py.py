@@ -106,6 +106,7 @@ def lib(path=None):
         fn = getattr(L, "orc_tap_" + name)
         fn.restype, fn.argtypes = fp, [C.c_void_p]
     L.orc_tap_filter_beg.restype, L.orc_tap_filter_beg.argtypes = ip, [C.c_void_p]
+    L.orc_tap_norm_stats.restype, L.orc_tap_norm_stats.argtypes = fp, [C.c_void_p, C.c_int, C.c_int]
     L.orc_ewc.argtypes = [C.c_int, C.c_int, C.c_int]
     L.orc_output_width.argtypes = [C.c_int] * 4
     L.orc_delta_apply.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp]
@@ -216,6 +217,20 @@ class OracleMfcc:
         per_row = {"frames": W2, "fft": 2 * W2, "mel": nb, "mfcc": dl}[name]
         p = getattr(self.L, "orc_tap_" + name)(self.h)
         return np.ctypeslib.as_array(p, shape=(rows * per_row,)).reshape(rows, per_row).copy()
+
+    def norm_stats(self):
+        """(mean, multiplier) of the normaliser instances after apply(): [groups][2][cols]; groups = 1 when the
+        statics are normalised before the deltas, else one per column group of the output row."""
+        dl = self.cfg.ceps_len + (1 if self.cfg.want_c0 else 0)
+        cols = dl if self.cfg.ceps_len > 0 else self.cfg.num_banks
+        groups = (1 + self.cfg.dyn) if self.cfg.norm_after_dyn else 1
+        out = np.empty((groups, 2, cols), np.float32)
+        for g in range(groups):
+            for k in range(2):
+                out[g, k] = np.ctypeslib.as_array(self.L.orc_tap_norm_stats(self.h, g, k), shape=(cols,))
+        if self.cfg.norm == NORM_CMN:   # mean subtraction only: the multiplier slot is unused (normalizercpu.cpp:72-76)
+            out[:, 1] = 1.0
+        return out
 
     def tables(self):
         W2, nb = self.fft_size, self.cfg.num_banks

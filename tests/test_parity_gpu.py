@@ -43,6 +43,73 @@ def groups_of(dyn):
     return {0: 1, 1: 2, 2: 3}[dyn]
 
 
+def stream_normalised_check(pkg, orc, pcm, ibs, what, norm, dyn, nad=True, alpha=1.0, block=0, **kw):
+    """Streams `pcm` block by block through the HIP extractor and the oracle, each with its norm = NONE twin, and
+    applies conftest.assert_normalised_close to every block (flush included): statistics from mfx_debug_read(5)
+    against the oracle's normaliser instances, un-normalised rows at 1e-4 / 1e-5, normalised rows within the bound
+    those imply.  Returns the HIP extractor's normalised rows."""
+    from conftest import assert_normalised_close
+    m, cfg, w = make_pair(pkg, orc, ibs, norm=norm, dyn=dyn, nad=nad, **kw)
+    m0, cfg0, _ = make_pair(pkg, orc, ibs, norm=0, dyn=dyn, nad=nad, **kw)
+    o, o0 = orc.OracleMfcc(cfg, w), orc.OracleMfcc(cfg0, w)
+    g = groups_of(dyn)
+    rows, pos, limit, blk = [], 0, (block or m.get_input_buffer_size()), 0
+    while True:
+        last = pos >= pcm.size
+        if last:
+            n = m.flush()
+            assert n == o.flush() == m0.flush() == o0.flush()
+        else:
+            piece = pcm[pos:pos + limit]
+            n = m.set_input(piece)
+            assert n == o.set_input(piece) == m0.set_input(piece) == o0.set_input(piece)
+            pos += limit
+        if n > 0:
+            for e in (m, o, m0, o0):
+                e.set_alpha(alpha)
+                e.apply()
+            y = m.get_output_data(n)
+            cols = y.shape[1] // g
+            st = m.debug_read(5).reshape(-1, 2, cols)
+            assert_normalised_close(y, o.get_output_data(n), m0.get_output_data(n), o0.get_output_data(n), st,
+                                    o.norm_stats(), g, nad, "%s block %d%s" % (what, blk, " (flush)" if last else ""),
+                                    norm=norm)
+            rows.append(y)
+        blk += 1
+        if last:
+            break
+    return np.concatenate(rows)
+
+
+def batch_normalised_check(pkg, orc, pcm, what, norm, dyn, nad=True, **kw):
+    """One utterance through the batch entry (default batch_norm_stats = 0) against the oracle fed the utterance as
+    ONE block with the flush rows at their correct place (bug_compat off): the three-part check of conftest.py with
+    the statistics of mfx_debug_read(6)."""
+    from conftest import assert_normalised_close
+    ibs = pcm.size + 1000
+    m, cfg, w = make_pair(pkg, orc, ibs, norm=norm, dyn=dyn, nad=nad, **kw)
+    m0, cfg0, _ = make_pair(pkg, orc, ibs, norm=0, dyn=dyn, nad=nad, **kw)
+    g = groups_of(dyn)
+    outs = []
+    for e in (m, m0):
+        e.batch_plan([0], [pcm.size])
+        outs.append(e.batch_run_host(pcm))
+    y, x = outs
+    cols = y.shape[1] // g
+    st = m.debug_read(6).reshape(-1, 1, 2, cols)[:, 0]
+    x_want = orc.run_utterance(cfg0, pcm, w, bug_compat=False)
+    o = orc.OracleMfcc(cfg, w, bug_compat=False)
+    n = o.set_input(pcm)
+    o.apply()
+    rows, st_want = [o.get_output_data(n)], o.norm_stats()
+    nf = o.flush()
+    if nf > 0:
+        o.apply()
+        rows.append(o.get_output_data(nf))
+    assert_normalised_close(y, np.concatenate(rows), x, x_want, st, st_want, g, nad, what, norm=norm)
+    return y
+
+
 # ---------------------------------------------------------------------------------------------
 # C1: the reference's own audio file
 # ---------------------------------------------------------------------------------------------
@@ -114,13 +181,12 @@ def test_c1_batch_entry(pkg, orc, a0001):
 
 def test_a1_reference_main_defaults(pkg, orc, a1):
     """ASR_OCL.cpp:560 defaults: 15 banks, 12 ceps + c0 (last column), CVN, no dyn."""
-    m, cfg, w = make_pair(pkg, orc, 32000, nb=15, nc=12, c0=True, norm=2, dyn=0)
-    got = m.process_stream(a1)
-    want = orc.run_utterance(cfg, a1, w)
-    assert got.shape == (504, 13)
-    assert_close(got, want, "a1 main defaults (CVN)", tol_max=2e-4, tol_l2=3e-5)
+    total = stream_normalised_check(pkg, orc, a1, 32000, "a1 main defaults (CVN)", nb=15, nc=12, c0=True, norm=2, dyn=0)
+    assert total.shape == (504, 13)
+    # the committed fixture is the oracle's own output: a regression pin on the same three-part check's result
     gold = np.load(os.path.join(GOLDEN, "c1_a0001_oracle.npz"))["a1_main_defaults"]
-    assert_close(got, gold, "a1 vs committed fixture", tol_max=2e-4, tol_l2=3e-5)
+    want = orc.run_utterance(orc.make_config(32000, num_banks=15, ceps_len=12, want_c0=True, norm=2, dyn=0), a1)
+    assert np.array_equal(want, gold)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -214,30 +280,63 @@ def test_dyn_and_output_layout(pkg, orc, dyn, l1, l2, nc, c0):
 @pytest.mark.parametrize("norm", [1, 2, 3])
 @pytest.mark.parametrize("nad", [True, False])
 def test_normalisation(pkg, orc, norm, nad):
+    """Streaming: per-block statistics as the reference (normalizercpu.cpp:22-27), the flush block re-using the
+    previous block's (mfcccpu.cpp:384,388).  Every block passes the three-part check of conftest.py."""
     pcm = synth_utterance(50000, 11)
-    m, cfg, w = make_pair(pkg, orc, 16000, nb=26, norm=norm, dyn=2, nad=nad)
-    got = m.process_stream(pcm)
-    want = orc.run_utterance(cfg, pcm, w)
-    # normalised features are O(1); variance/extreme statistics amplify float32 noise slightly
-    assert_close(got, want, "stream norm=%d nad=%s" % (norm, nad), tol_max=3e-4, tol_l2=5e-5, groups=3)
-    # batch: one block per utterance == a single-block stream with the corrected flush rows
-    cfg1 = orc.make_config(100000, num_banks=26, ceps_len=13, norm=norm, dyn=2, norm_after_dyn=nad)
-    o = orc.OracleMfcc(cfg1, w, bug_compat=False)
-    n = o.set_input(pcm)
-    o.apply()
-    head = o.get_output_data(n)
-    m.batch_plan([0], [pcm.size])
-    b = m.batch_run_host(pcm)
-    if nad:
-        # the reference normalises each block with its own statistics, so only the first block of
-        # the oracle (N-D frames) is comparable after rescaling; check the invariants instead
-        g = b.reshape(b.shape[0], 3, -1)
-        assert np.abs(g.mean(0)).max() < 1e-4
-        if norm == 2:
-            np.testing.assert_allclose(g.std(0, ddof=1), 1.0, atol=1e-3)
-        if norm == 3:
-            np.testing.assert_allclose(np.abs(g).max(0), 1.0, atol=1e-4)
-    assert head.shape[0] == b.shape[0] - 6
+    got = stream_normalised_check(pkg, orc, pcm, 16000, "stream norm=%d nad=%s" % (norm, nad), norm=norm, dyn=2, nad=nad,
+                                  nb=26)
+    assert got.shape == (311, 39)
+
+
+@pytest.mark.parametrize("norm", [1, 2, 3])
+@pytest.mark.parametrize("nad", [True, False])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_batch_normalisation_semantics(pkg, orc, norm, nad, mode):
+    """Batch entry.  batch_norm_stats = 0 (default): what the reference delivers for an utterance it consumes as ONE
+    block (its default sample_limit holds ten minutes): statistics over the T - D rows of that block, re-used for the
+    D flush rows (mfcccpu.cpp:377-388,395-407; normalizercpu.cpp:22-27) -- compared with the oracle run as a single
+    block (flush rows at their correct place, i.e. B1 fixed).  batch_norm_stats = 1: statistics over all T rows
+    (what no reference run produces; checked against the definition in float64)."""
+    from conftest import assert_normalised_close
+    pcm = synth_utterance(50000, 11)
+    w = pkg.reference_window(400)
+    mk = lambda nrm: pkg.MfccHip(100000, 400, 160, 26, 16000.0, 64.0, 8000.0, 13, False, 22.0, nrm, 2, 3, 3, nad,
+                                 device=0, batch_norm_stats=mode)
+    m, m0 = mk(norm), mk(0)
+    outs = []
+    for e in (m, m0):
+        e.set_window(w)
+        e.batch_plan([0], [pcm.size])
+        outs.append(e.batch_run_host(pcm))
+    y, x = outs
+    T = y.shape[0]
+    st = m.debug_read(6).reshape(-1, 1, 2, 13)[:, 0]
+    cfg = orc.make_config(100000, num_banks=26, ceps_len=13, norm=norm, dyn=2, norm_after_dyn=nad)
+    cfg0 = orc.make_config(100000, num_banks=26, ceps_len=13, norm=0, dyn=2, norm_after_dyn=nad)
+    x_want = orc.run_utterance(cfg0, pcm, w, bug_compat=False)
+    if mode == 0 or not nad:
+        # (before the deltas the reference's first block normalises all T rows with context: both modes coincide)
+        o = orc.OracleMfcc(cfg, w, bug_compat=False)
+        n = o.set_input(pcm)
+        assert n == T - 6
+        o.apply()
+        head, st_want = o.get_output_data(n), o.norm_stats()
+        assert o.flush() == 6
+        o.apply()
+        y_want = np.concatenate([head, o.get_output_data(6)])
+    else:
+        xs = x_want.astype(np.float64).reshape(T, 3, 13)
+        mean = xs.mean(0)
+        if norm == 1:
+            mult = np.ones_like(mean)
+        elif norm == 2:
+            mult = 1.0 / xs.std(0, ddof=1)
+        else:
+            mult = 1.0 / np.maximum(np.abs(xs.min(0) - mean), np.abs(xs.max(0) - mean))
+        st_want = np.stack([mean, mult], axis=1)
+        y_want = ((xs - mean) * mult).reshape(T, 39)
+    assert_normalised_close(y, y_want, x, x_want, st, st_want, 3, nad, "batch norm=%d nad=%s mode=%d" % (norm, nad, mode),
+                            norm=norm)
 
 
 @pytest.mark.parametrize("alpha", [0.88, 1.0, 1.12])
@@ -305,7 +404,11 @@ def test_vtln_sweep_in_one_call(pkg, orc, norm, nad):
             assert_close(g, want, "sweep alpha %.2f" % a, groups=3)
             assert np.array_equal(g, np.concatenate(ref_same_handle[i]))
         else:
-            assert_close(g, want, "sweep alpha %.2f norm %d" % (a, norm), tol_max=1e-3, tol_l2=2e-4, groups=3)
+            # a fresh handle streamed with this alpha alone passes the three-part normalisation check against the
+            # oracle block by block; the sweep's rows for that alpha are the same bits
+            alone = stream_normalised_check(pkg, orc, pcm, 20000, "alpha %.2f alone, norm %d" % (a, norm), norm=norm,
+                                            dyn=2, nad=nad, alpha=a, block=16000)
+            assert np.array_equal(g, alone)
     with pytest.raises(Exception):
         m.get_output_data_alpha(len(alphas), 1)
 
@@ -761,16 +864,36 @@ def test_random_configuration(pkg, orc, case):
                           nc=c["nc"], c0=c["c0"], norm=c["norm"], dyn=c["dyn"], l1=c["l1"], l2=c["l2"])
     assert m.fft_size() == c["fft"]
     g = groups_of(c["dyn"])
-    # CMN/CVN: the output is rescaled by 1/sigma of each column, which amplifies the float32 noise floor of
-    # the un-normalised features (a few 1e-6 of their scale) by scale/sigma -- large for the nearly
-    # constant delta-delta columns -- so the comparison is looser there: the un-normalised bar (1e-5 of the
-    # signal scale in L2) times scale/sigma of order 30 gives a few 1e-4 of the unit variance.
-    # Un-normalised configurations keep the 1e-4 / 1e-5 bar.
-    tol = dict(tol_max=2e-3, tol_l2=5e-4) if c["norm"] else {}
-    assert_close(m.process_stream(pcm), orc.run_utterance(cfg, pcm, w), "stream", groups=g, **tol)
-    if not c["norm"]:   # batch normalisation is per utterance, the reference's is per block
-        m.batch_plan([0], [pcm.size])
-        assert_close(m.batch_run_host(pcm), orc.run_utterance(cfg, pcm, w, bug_compat=False), "batch", groups=g)
+    if c["norm"]:
+        # normalised: statistics, un-normalised twin and derived bound, block by block (conftest.py); the batch entry
+        # against the oracle fed the utterance as one block
+        kw = dict(W=c["W"], S=c["S"], nb=c["nb"], sr=c["sr"], low=c["low"], high=c["high"], nc=c["nc"], c0=c["c0"],
+                  l1=c["l1"], l2=c["l2"])
+        stream_normalised_check(pkg, orc, pcm, n, "stream", norm=c["norm"], dyn=c["dyn"], **kw)
+        batch_normalised_check(pkg, orc, pcm, "batch", norm=c["norm"], dyn=c["dyn"], **kw)
+        return
+    assert_close(m.process_stream(pcm), orc.run_utterance(cfg, pcm, w), "stream", groups=g)
+    m.batch_plan([0], [pcm.size])
+    assert_close(m.batch_run_host(pcm), orc.run_utterance(cfg, pcm, w, bug_compat=False), "batch", groups=g)
+
+
+def test_last_frame_ends_on_an_odd_last_sample(pkg, orc):
+    """An utterance with an ODD number of samples whose last frame ends exactly on the last sample, at the very end of
+    the PCM array: the last sample lies in a 32-bit word that is half past the end.  (Found by the widened random
+    sweep in round 2: the buffer range check dropped that word and the last frame lost its last sample.)"""
+    W, S = 489, 132
+    n = 128 * S + W                                   # 129 frames, the last one ends on sample n - 1; n is odd
+    assert n % 2 == 1
+    pcm = synth_utterance(n, 1003, sr=22050.0)
+    m, cfg, w = make_pair(pkg, orc, n + 1000, W=W, S=S, nb=40, sr=22050.0, nc=13, dyn=0)
+    m.batch_plan([0], [n])
+    got = m.batch_run_host(pcm)
+    assert got.shape == (129, 13)
+    assert_close(got, orc.run_utterance(cfg, pcm, w, bug_compat=False), "odd tail")
+    # odd offset as well (unaligned load path): the same utterance one sample into the array
+    pcm1 = np.concatenate([np.zeros(1, np.int16), pcm])
+    m.batch_plan([1], [n])
+    assert_close(m.batch_run_host(pcm1), got, "odd tail, odd offset", tol_max=1e-6, tol_l2=1e-6)
 
 
 def test_batch_overlap_mode_is_bit_identical(pkg, orc):
