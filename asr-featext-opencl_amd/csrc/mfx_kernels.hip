@@ -1468,6 +1468,15 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
                 mag_hi[j] = __builtin_amdgcn_sqrtf(br * br + bi * bi); // |X[M - k]| / W2
             }
             wave_sync();
+#if defined(MFX_ABLATE_REG) && MFX_ABLATE_REG >= 1
+            if (FUSED) { // dev-only: stop after the magnitudes (keeps them live)
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j <= NP; ++j) acc += mag_lo[j] + mag_hi[j];
+                if (lane < p.cols) (p.feat + (ch.out_row + f) * (int64_t)p.feat_pitch)[lane] = acc;
+                continue;
+            }
+#endif
             if (FUSED) {
                 float *mag = (float *)buf; // in place: every complex point has been read
 #pragma unroll
