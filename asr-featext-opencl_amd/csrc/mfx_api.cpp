@@ -76,6 +76,12 @@ struct mfx_handle {
     DevBuf<float> d_mel_lane_w, d_dct_t;
     DevBuf<int32_t> d_mel_lane_start, d_mel_lane_fid;
     MelLanePlan plan;
+    // wave-per-frame kernels (k_front_reg, fused): 64-lane mel plan + DCT operands for the matrix pipe
+    MelWavePlan wplan;
+    bool wplan_ok = false;
+    DevBuf<float> d_mel64_w, d_dct_b;
+    DevBuf<int32_t> d_mel64_start, d_mel64_fid;
+    int dct_tiles = 0, dct_ksteps = 0;
     int dct_stride = 0, nb_pad = 0;
     bool fused_ok = false;
     std::vector<float> h_dct;
@@ -203,6 +209,16 @@ int refresh_mel(mfx_handle *h)
         fill_front(h, probe);
         h->fused_ok = front512_lds_bytes(probe) <= 160 * 1024;
     }
+    h->wplan_ok = false;
+    if (h->W2 >= 1024 && h->W2 <= 2048) { // the fused long-transform kernel walks the filters on the frame's 64 lanes
+        const int M = h->W2 / 2, MP = M + (M >> (h->W2 == 1024 ? 3 : 4));
+        if (build_mel_wave_plan(t, h->nb, h->W2, /*max_read_bin=*/2 * MP - 1, h->wplan)) {
+            HIP_TRY(h, upload(h->d_mel64_w, h->wplan.w));
+            HIP_TRY(h, upload(h->d_mel64_start, h->wplan.start));
+            HIP_TRY(h, upload(h->d_mel64_fid, h->wplan.fid));
+            h->wplan_ok = true;
+        }
+    }
     h->table_alpha = h->alpha;
     return MFX_OK;
 }
@@ -241,6 +257,15 @@ void fill_front(const mfx_handle *h, FrontParams &p)
     p.mel_row_stride = h->plan.row_stride;
     for (int i = 0; i < 8; ++i) p.mel_L[i] = h->plan.L[i];
     p.dct_mode = (h->ceps > 0 && h->cols <= 16 && h->nb <= 40) ? 1 : 0; // DCT on the matrix pipe
+    p.mel64_w = h->d_mel64_w.p;
+    p.mel64_start = h->d_mel64_start.p;
+    p.mel64_fid = h->d_mel64_fid.p;
+    p.mel64_rounds = h->wplan_ok ? h->wplan.rounds : 0;
+    p.mel64_row_stride = h->wplan_ok ? h->wplan.row_stride : 0;
+    for (int i = 0; i < 8; ++i) p.mel64_L[i] = h->wplan.L[i];
+    p.dct_b = h->ceps > 0 ? h->d_dct_b.p : nullptr;
+    p.dct_tiles = h->dct_tiles;
+    p.dct_ksteps = h->dct_ksteps;
     p.dct_stride = h->dct_stride;
     p.nb_pad = h->nb_pad > 0 ? h->nb_pad : ((h->nb + 3) & ~3);
 }
@@ -365,6 +390,10 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_sweep_items.release();
     h->d_sweep_pieces.release();
     h->d_mel_lane_w.release();
+    h->d_mel64_w.release();
+    h->d_mel64_start.release();
+    h->d_mel64_fid.release();
+    h->d_dct_b.release();
     h->d_dct_t.release();
     h->d_mel_lane_start.release();
     h->d_mel_lane_fid.release();
@@ -532,6 +561,11 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
             build_dct_matrix(h->nb, h->ceps, cfg->want_c0 != 0, cfg->lift_coef, m);
             if (upload(h->d_dct, m) != hipSuccess) return bail(MFX_ERR_DEVICE);
             h->h_dct = m;
+            {
+                std::vector<float> ob;
+                build_dct_mfma_operands(m, h->nb, h->dl, h->dct_tiles, h->dct_ksteps, ob);
+                if (upload(h->d_dct_b, ob) != hipSuccess) return bail(MFX_ERR_DEVICE);
+            }
             if (h->fast512) {
                 std::vector<float> mt;
                 build_dct_transposed(m, h->nb, h->dl, h->dct_stride, h->nb_pad, mt);
@@ -1333,7 +1367,8 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
     const bool fused512 = h->fast512 && h->fused_ok;
     // (up to 2048 points the fused form saves the spectrum's round trip through HBM -- 8 KB per frame at 2048
     // points; at 4096 points the tables + per-wave buffers no longer leave enough waves per CU)
-    const bool fusedgen = !fused512 && h->W2 <= 2048 && front_wave_lds_bytes(p, true) <= 160 * 1024;
+    const bool fusedgen = !fused512 && h->W2 <= 2048 && (h->W2 < 1024 || h->wplan_ok) &&
+                          front_wave_lds_bytes(p, true) <= 160 * 1024;
     // With deltas on, the front end writes its statics as compact 64-byte rows into a scratch buffer
     // and the delta kernel emits whole [static | d | dd] rows: every HBM write is then a full line
     // (13-float row pieces at a 156-byte pitch cost 1.5x their size in 32-byte sectors).

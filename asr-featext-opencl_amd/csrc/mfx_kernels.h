@@ -86,6 +86,15 @@ struct FrontParams {
                                   //    4 frames (cols <= 16, num_banks <= 40; matrix from `dct`, held in registers)
     int32_t mel_rounds, mel_row_stride, dct_stride, nb_pad;
     int32_t mel_L[8];
+    // wave-per-frame lane plan (k_front_reg fused): filters dealt to the 64 lanes of the frame's wave in rounds
+    const float *mel64_w;         // [64][mel64_row_stride]
+    const int32_t *mel64_start;   // [mel64_rounds][64]
+    const int32_t *mel64_fid;     // [mel64_rounds][64]
+    int32_t mel64_rounds, mel64_row_stride;
+    int32_t mel64_L[8];
+    // DCT on the matrix pipe: B operands [dct_tiles][dct_ksteps][64] (build_dct_mfma_operands), read from L1 / L2
+    const float *dct_b;
+    int32_t dct_tiles, dct_ksteps;
     int32_t num_banks;
     int32_t dct_len;
     int32_t cols;             // dct_len, or num_banks when ceps_len == 0

@@ -1267,6 +1267,20 @@ __global__ void __launch_bounds__(256) k_front_wave(FrontParams p)
 //   FUSED (M = 512): mel -> log -> DCT from the magnitudes in LDS; else magnitudes to the HBM spectrum.
 //   PAIR: mono, even shift / offsets / window length -> two samples per 32-bit load.
 // ------------------------------------------------------------------------------------------------
+// Log mel energies of 4 consecutive frames wait in LDS for the DCT on the matrix pipe: rows of lm_stride(nb) floats,
+// stride = 8 mod 32 so that the 4 frames' operand reads fall on distinct banks, at least one spare word per row (idle
+// lanes of the mel walk park their value there).
+__host__ __device__ inline int lm_stride(int nb)
+{
+    int x = ((nb + 3) & ~3) + 1;
+    while ((x & 31) != 8) ++x;
+    return x;
+}
+
+#ifndef MFX_REG10_THREADS
+#define MFX_REG10_THREADS 512   // threads per block of the fused 2048-point build (sets its register budget)
+#endif
+
 // 8-point forward DFT in registers, natural order in and out
 __device__ __forceinline__ void fft8(float2 (&x)[8])
 {
@@ -1346,7 +1360,7 @@ __device__ __forceinline__ void stockham_pass(float2 *buf, const float2 *s_tw, i
 // HALF: the window is at most M samples (a short window zero padded to the transform, BASELINE configs[2]): the
 // upper half of every lane's sample pairs is zero at compile time and pass 1 sheds the arithmetic on it.
 template <int LOG2M, bool FUSED, bool PAIR, bool HALF>
-__global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 512 : 1024) k_front_reg(FrontParams p)
+__global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? MFX_REG10_THREADS : 1024) k_front_reg(FrontParams p)
 {
     constexpr int M = 1 << LOG2M, NV = M / 64;
     constexpr int R1 = (LOG2M == 9) ? 8 : 16, R2 = R1, R3 = M / (R1 * R2);
@@ -1359,17 +1373,17 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
     float2 *s_tw = (float2 *)smem;                 // pass 1 [R1-1][M/R1], then pass 2 [R2-1][M/(R1 R2)]; M slots reserved
     float2 *s_cs = s_tw + M;                       // [M/2 + 1]  -i W_{2M}^k (one per bin pair), padded to even
     float2 *s_win = s_cs + (M / 2 + 2);            // [M]   (w[2n], w[2n+1]) * 0.5 / W2
-    float *s_mw = (float *)(s_win + M);                        // per-piece mel weights
-    int4 *s_items = (int4 *)(s_mw + (FUSED ? p.mel_wlen : 0)); // mel work plan: items [K][64], then pieces [nb]
-    int *s_pieces = (int *)s_items + p.mel_K * 256;
-    float *s_dct = (float *)((int *)s_items + (FUSED ? mel_plan_words(nb, p.mel_K) : 0));
-    const int dl4 = (dl + 3) & ~3;               // DCT rows padded to whole 16-byte words in LDS
-    const int dct_floats = (FUSED && p.dct) ? nb * dl4 : 0;
-    const int dct_pad = dct_floats;
-    const int nb_pad = FUSED ? mel_scratch_floats(nb, p.cols) : 0;
-    float *s_wave = s_dct + dct_pad + wave * (2 * MP + nb_pad);
+    // FUSED: the mel walk's per-lane weight rows and plan (MelWavePlan), then per wave the complex buffer and the
+    // log mel energies of 4 frames (the DCT runs on the matrix pipe once per 4 frames)
+    const int RS = FUSED ? p.mel64_row_stride : 0, rounds = FUSED ? p.mel64_rounds : 0;
+    float *s_mw = (float *)(s_win + M);                        // [64][RS]
+    int *s_mst = (int *)(s_mw + 64 * RS);                      // [rounds][64]
+    int *s_mfid = s_mst + 64 * rounds;                         // [rounds][64]
+    const int nbp = FUSED ? lm_stride(nb) : 0;
+    float *s_wave = (float *)(s_mfid + 64 * rounds) + wave * (2 * MP + 4 * nbp);
     float2 *buf = (float2 *)s_wave;
-    float *s_mel = s_wave + 2 * MP;
+    float *lm = s_wave + 2 * MP;                               // [4][nbp]
+    (void)dl;
 
     const float scale = p.scale; // 0.5 / W2, a power of two: folded into the window taps (exact)
     static_assert(NT1 + NT2 <= M, "pass tables fit the reserved slots");
@@ -1380,20 +1394,21 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
     }
     for (int i = tid; i <= M / 2; i += blockDim.x) s_cs[i] = ((const float2 *)p.twid_split)[i];
     if (FUSED) {
-        for (int i = tid; i < p.mel_wlen; i += blockDim.x) s_mw[i] = p.mel_item_w[i];
-        for (int i = tid; i < p.mel_K * 256; i += blockDim.x) ((int *)s_items)[i] = p.mel_items[i];
-        for (int i = tid; i < nb; i += blockDim.x) s_pieces[i] = p.mel_pieces[i];
-        for (int i = tid; i < dct_floats; i += blockDim.x) {
-            const int m = i / dl4, c = i - m * dl4;
-            s_dct[i] = c < dl ? p.dct[m * dl + c] : 0.f;
+        for (int i = tid; i < 64 * RS; i += blockDim.x) s_mw[i] = p.mel64_w[i];
+        for (int i = tid; i < 64 * rounds; i += blockDim.x) {
+            s_mst[i] = p.mel64_start[i];
+            s_mfid[i] = p.mel64_fid[i];
         }
+        for (int i = lane; i < 4 * nbp; i += 64) lm[i] = 0.f; // words the walk never writes meet zero operands: keep them finite
     }
     __syncthreads();
 
     const int ch_n = p.channels, W = p.window_size;
     for (int c = blockIdx.x * n_waves + wave; c < p.n_chunks; c += gridDim.x * n_waves) {
         const Chunk ch = p.chunks[c];
-        for (int f = 0; f < ch.n_frames && (ch.out_row + f) < p.row_limit; ++f) {
+        const int64_t rows_left = p.row_limit - ch.out_row;
+        const int nf = (int)(rows_left < ch.n_frames ? (rows_left < 0 ? 0 : rows_left) : ch.n_frames);
+        for (int f = 0; f < nf; ++f) {
             const int64_t s0 = ch.pcm_off + (int64_t)f * p.shift;
             // ---- framing + window, straight into the registers of pass 1: z[n], n = lane + 64 j
             float2 v[NV];
@@ -1487,9 +1502,77 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? 5
                 }
                 if (lane == 0) mag[M / 2] = mag_lo[NP];
                 wave_sync();
-                mel_log_dct<64>(mag, s_mel, lane, s_mw, s_items, s_pieces, p.mel_K, p.dct ? s_dct : nullptr, nb, dl, p.cols,
-                                p.feat + (ch.out_row + f) * (int64_t)p.feat_pitch);
+                // ---- mel filterbank: per round every lane walks ONE filter's bins in ascending order, one chain of
+                // multiply-adds (mfcccpu.cpp:192-220).  Weights come from the lane's own zero-padded row (16-byte reads,
+                // disjoint bank quads), magnitudes as 8-byte reads from even starts the host spread over the banks.
+                {
+                    float *lmf = lm + (f & 3) * nbp;
+                    const float *wrow = s_mw + lane * RS;
+                    for (int r = 0; r < rounds; ++r) {
+                        const int L = p.mel64_L[r];
+                        const float *mg = mag + s_mst[r * 64 + lane];
+                        const int fid = s_mfid[r * 64 + lane];
+                        float acc = 0.f;
+                        for (int s2 = 0; s2 < L; s2 += 8) {
+                            const float4 w0 = lds_read_b128((const float4 *)(wrow + s2));
+                            const float4 w1 = lds_read_b128((const float4 *)(wrow + s2 + 4));
+                            float2 mm[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) mm[q] = lds_read_b64((const float2 *)(mg + s2 + 2 * q));
+                            acc += w0.x * mm[0].x;
+                            acc += w0.y * mm[0].y;
+                            acc += w0.z * mm[1].x;
+                            acc += w0.w * mm[1].y;
+                            acc += w1.x * mm[2].x;
+                            acc += w1.y * mm[2].y;
+                            acc += w1.z * mm[3].x;
+                            acc += w1.w * mm[3].y;
+                        }
+                        wrow += L;
+                        lmf[fid >= 0 ? fid : nbp - 1] = MFX_LOG(fmaxf(acc, 1e-30f)); // idle lane: the row's spare word
+                    }
+                }
                 wave_sync();
+                // ---- every 4th frame (and at the chunk's end): DCT-II + lifter of the waiting frames on the matrix pipe,
+                // D[row][c] = sum_m A[row][m] B[m][c] with frame g in rows 4g..4g+3 (all lanes read valid energies), so
+                // register 0 of the result is out[g][c] on lane (g, c); tiles of 16 output columns, K steps of 4 bands,
+                // two accumulator chains.  B operands come from L1 / L2 (p.dct_b), A operands from the rows above.
+                if ((f & 3) == 3 || f == nf - 1) {
+                    const int g0 = f & ~3, gcount = f - g0 + 1;
+                    const int gi = lane >> 4, n = lane & 15;
+                    float *orow = p.feat + (ch.out_row + g0 + (gi < gcount ? gi : 0)) * (int64_t)p.feat_pitch;
+                    if (p.dct_b) {
+                        const float *arow = lm + (n >> 2) * nbp + gi;
+                        const int ks = p.dct_ksteps;
+                        for (int t = 0; t < p.dct_tiles; ++t) {
+                            const float *bp = p.dct_b + (int64_t)t * ks * 64 + lane;
+                            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+                            // K steps in batches of 8: the batch's operand loads (8 from L1 / L2, 8 from LDS) are all in
+                            // flight before its first matrix instruction; steps past the matrix get zero operands
+                            for (int j0 = 0; j0 < ks; j0 += 8) {
+                                float bv[8], av[8];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    const bool in = j0 + u < ks;
+                                    bv[u] = in ? bp[(j0 + u) * 64] : 0.f;
+                                    av[u] = arow[in ? 4 * (j0 + u) : 0];
+                                }
+#pragma unroll
+                                for (int u = 0; u < 8; u += 2) {
+                                    d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], d0, 0, 0, 0);
+                                    d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], d1, 0, 0, 0);
+                                }
+                            }
+                            const int col = 16 * t + n;
+                            if (gi < gcount && col < p.cols) orow[col] = d0[0] + d1[0];
+                        }
+                    } else { // no DCT: the log mel energies are the features
+                        for (int g = 0; g < gcount; ++g)
+                            for (int cc = lane; cc < p.cols; cc += 64)
+                                (p.feat + (ch.out_row + g0 + g) * (int64_t)p.feat_pitch)[cc] = lm[g * nbp + cc];
+                    }
+                    wave_sync();
+                }
             } else {
                 float *dst = p.spec + (ch.out_row + f) * (int64_t)p.spec_pitch;
 #pragma unroll
@@ -1919,12 +2002,9 @@ size_t front_reg_lds_floats(const FrontParams &p, bool fused, int n_waves)
 {
     const size_t M = (size_t)p.fft_size >> 1;
     size_t f = 2 * M + 2 * (M / 2 + 2) + 2 * M; // pass twiddles, split twiddles, window pairs
-    if (fused) {
-        f += (size_t)p.mel_wlen + mel_plan_words(p.num_banks, p.mel_K);
-        f += p.dct ? (size_t)p.num_banks * ((p.dct_len + 3) & ~3) : 0;
-    }
+    if (fused) f += (size_t)64 * p.mel64_row_stride + (size_t)128 * p.mel64_rounds; // lane weight rows, starts + filter ids
     const size_t MP = M + (M >> (p.fft_size == 1024 ? 3 : 4)); // padded buffer (pad_idx)
-    f += (size_t)n_waves * (2 * MP + (fused ? mel_scratch_floats(p.num_banks, p.cols) : 0));
+    f += (size_t)n_waves * (2 * MP + (fused ? 4 * lm_stride(p.num_banks) : 0));
     return f;
 }
 
@@ -1933,7 +2013,8 @@ int front_reg_waves(const FrontParams &p, bool fused)
 {
     // (4096 points: 4 waves -- the kernel is built for 256 threads there, its 32 points per lane need the registers)
     // (2048 points fused: 8 waves -- its tables leave no room for more, and the build allows 256 registers there)
-    for (int nw = p.fft_size >= 4096 ? 4 : (p.fft_size == 2048 && fused) ? 8 : 16; nw >= 4; nw >>= 1)
+    const int top = p.fft_size >= 4096 ? 4 : (p.fft_size == 2048 && fused) ? MFX_REG10_THREADS / 64 : 16;
+    for (int nw = top; nw >= 4; nw = nw > 8 ? nw - 2 : nw >> 1)
         if (front_reg_lds_floats(p, fused, nw) * sizeof(float) <= 160 * 1024) return nw;
     return 0;
 }

@@ -168,6 +168,76 @@ bool build_mel_lane_plan(const MelTable &t, int num_banks, int fft_size, int max
     return true;
 }
 
+bool build_mel_wave_plan(const MelTable &t, int num_banks, int fft_size, int max_read_bin, MelWavePlan &out)
+{
+    std::vector<int> order(num_banks);
+    for (int m = 0; m < num_banks; ++m) order[m] = m;
+    auto span = [&](int m) { return t.beg[m + 2] - t.beg[m]; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return span(a) > span(b); });
+    out.rounds = (num_banks + 63) / 64;
+    if (out.rounds > 8) return false;
+    out.start.assign((size_t)64 * out.rounds, 0);
+    out.fid.assign((size_t)64 * out.rounds, -1);
+    int total = 0;
+    for (int r = 0; r < out.rounds; ++r) {
+        // An 8-byte read is served in two groups of 32 lanes over 32 bank pairs: a group is conflict free when
+        // (start / 2) mod 32 differs from lane to lane, so a clashing filter begins a few pairs early (zero weights).
+        bool used[2][32] = {{false}};
+        int longest = 0;
+        for (int j = 0; j < 64; ++j) {
+            const int idx = r * 64 + j;
+            if (idx >= num_banks) continue;
+            const int m = order[idx];
+            const int b0 = t.beg[m], b1 = t.beg[m + 2];
+            int start = b0 & ~1;
+            for (int d = 0; d < 6; ++d) {
+                const int cand = (b0 & ~1) - 2 * d;
+                if (cand < 0) break;
+                if (!used[j >> 5][(cand >> 1) & 31]) {
+                    start = cand;
+                    break;
+                }
+            }
+            used[j >> 5][(start >> 1) & 31] = true;
+            out.start[r * 64 + j] = start;
+            out.fid[r * 64 + j] = m;
+            longest = std::max(longest, b1 - start);
+        }
+        out.L[r] = std::max(8, (longest + 7) & ~7);
+        total += out.L[r];
+    }
+    out.row_stride = stride_4odd(total);
+    out.w.assign((size_t)64 * out.row_stride, 0.0f);
+    int base = 0;
+    for (int r = 0; r < out.rounds; ++r) {
+        for (int j = 0; j < 64; ++j) {
+            const int m = out.fid[r * 64 + j];
+            if (m < 0) continue;
+            const int start = out.start[r * 64 + j];
+            if (start + out.L[r] - 1 > max_read_bin) return false;
+            const float *row = t.weights.data() + (size_t)(m & 1) * fft_size;
+            float *dst = out.w.data() + (size_t)j * out.row_stride + base;
+            for (int k = t.beg[m]; k < t.beg[m + 2]; ++k) dst[k - start] = row[k];
+        }
+        base += out.L[r];
+    }
+    return true;
+}
+
+void build_dct_mfma_operands(const std::vector<float> &dct, int num_banks, int dct_len, int &tiles, int &ksteps,
+                             std::vector<float> &out)
+{
+    tiles = (dct_len + 15) / 16;
+    ksteps = (num_banks + 3) / 4;
+    out.assign((size_t)tiles * ksteps * 64, 0.0f);
+    for (int tl = 0; tl < tiles; ++tl)
+        for (int j = 0; j < ksteps; ++j)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = 4 * j + (lane >> 4), c = 16 * tl + (lane & 15);
+                if (m < num_banks && c < dct_len) out[((size_t)tl * ksteps + j) * 64 + lane] = dct[(size_t)m * dct_len + c];
+            }
+}
+
 void build_dct_transposed(const std::vector<float> &dct, int num_banks, int dct_len, int &stride, int &nb_pad,
                           std::vector<float> &out)
 {

@@ -58,6 +58,27 @@ struct MelLanePlan {
 // would read past `max_read_bin`)
 bool build_mel_lane_plan(const MelTable &t, int num_banks, int fft_size, int max_read_bin, MelLanePlan &out);
 
+// The same plan for the wave-per-frame kernels (64 lanes share a frame; k_front_reg): rounds of 64 filters, longest
+// first, every lane walks its filter's bins in ascending order (the reference's summation order, mfcccpu.cpp:192-220).
+//   w     : [64][row_stride], row_stride / 4 odd: the 16 lanes of a 16-byte access group read disjoint bank quads
+//   start : [rounds][64] first bin read (even), fid : [rounds][64] filter or -1, L[r] bins per lane in round r (x8)
+struct MelWavePlan {
+    int rounds = 0;
+    int row_stride = 0;
+    int L[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<float> w;
+    std::vector<int32_t> start;
+    std::vector<int32_t> fid;
+};
+// false when it does not fit (more than 8 rounds, or a read past max_read_bin)
+bool build_mel_wave_plan(const MelTable &t, int num_banks, int fft_size, int max_read_bin, MelWavePlan &out);
+
+// B operands of the DCT on the matrix pipe (v_mfma_f32_16x16x4_f32), for every tile of 16 output columns and every
+// K step of 4 mel bands: out[(tile * ksteps + j) * 64 + lane] = dct[4 j + (lane >> 4)][16 tile + (lane & 15)],
+// zero beyond the matrix.  ksteps = ceil(num_banks / 4), tiles = ceil(dct_len / 16).
+void build_dct_mfma_operands(const std::vector<float> &dct, int num_banks, int dct_len, int &tiles, int &ksteps,
+                             std::vector<float> &out);
+
 // Transposed, padded DCT matrix for the 512-point kernel: [cols][stride], stride / 4 odd,
 // row c = column c of the [num_banks][dct_len] matrix followed by zeros.
 void build_dct_transposed(const std::vector<float> &dct, int num_banks, int dct_len, int &stride, int &nb_pad,
