@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mfx_kernels.h"
@@ -100,6 +101,9 @@ struct mfx_handle {
     int n_chunks_stream_max = 0;
     int16_t *h_stage = nullptr; // pinned
     size_t h_stage_n = 0;
+    float *h_out_stage = nullptr;         // pinned staging of get_output_data (allocated on first use)
+    size_t h_out_stage_n = 0;
+    hipEvent_t ev_copy[16] = {};          // chunk events of the pipelined device-to-host copy
     // VTLN sweep (mfx_apply_alphas): one filterbank, one static and one output block per alpha
     std::vector<float> sweep_alphas;      // alphas of the tables currently in d_sweep_w
     int sweep_cap = 0;                    // alphas the sweep buffers hold
@@ -433,6 +437,9 @@ extern "C" void mfx_destroy(mfx_handle *h)
         if (h->ev_tail[i]) (void)hipEventDestroy(h->ev_tail[i]);
     }
     if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->h_out_stage) (void)hipHostFree(h->h_out_stage);
+    for (auto &e : h->ev_copy)
+        if (e) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -726,6 +733,96 @@ extern "C" int mfx_set_window(mfx_handle *h, const float *window)
 namespace {
 
 // frame + window + FFT + magnitude over the first `wcnd` frames of the carry buffer
+// ---- host side of the streaming copies --------------------------------------------------------------------------
+// The drop-in interface hands over pageable host memory that the caller may overwrite on return (ASR_OCL.cpp:160-161,
+// 231,243), so a block goes through pinned staging.  The staging copy is split over a few threads when it is large
+// (one core moves ~10 GB/s, the link 50) and pipelined with the DMA in chunks; a caller buffer that is itself pinned
+// (hipHostMalloc / hipHostRegister, a pinned torch tensor) is used by the DMA directly.
+void host_copy(void *dst, const void *src, size_t bytes)
+{
+    const size_t kMin = (size_t)1 << 20;
+    const unsigned nt = (unsigned)std::min<size_t>(4, bytes / kMin);
+    if (nt <= 1) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t piece = ((bytes / nt) + 63) & ~(size_t)63;
+    std::thread th[3];
+    for (unsigned t = 1; t < nt; ++t) {
+        const size_t off = piece * t, len = t + 1 == nt ? bytes - off : piece;
+        th[t - 1] = std::thread([=] { std::memcpy((char *)dst + off, (const char *)src + off, len); });
+    }
+    std::memcpy(dst, src, piece);
+    for (unsigned t = 1; t < nt; ++t) th[t - 1].join();
+}
+
+bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError(); // plain pageable memory: not an error
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+constexpr size_t kCopyChunk = (size_t)4 << 20;
+
+// host block -> device, asynchronous on the stream; `src` is free for the caller when this returns
+int upload_block(mfx_handle *h, int16_t *d_dst, const int16_t *src, size_t samples, bool *direct)
+{
+    const size_t bytes = samples * sizeof(int16_t);
+    *direct = bytes >= kCopyChunk && is_pinned_host(src);
+    if (*direct) { // DMA straight from the caller's pinned buffer; the caller waits for it (wait_upload) before returning
+        HIP_TRY(h, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+        if (!h->ev_copy[0]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_copy[0], hipEventDisableTiming));
+        HIP_TRY(h, hipEventRecord(h->ev_copy[0], h->stream));
+        return MFX_OK;
+    }
+    for (size_t off = 0; off < bytes; off += kCopyChunk) { // staging copy of chunk c+1 runs under the DMA of chunk c
+        const size_t len = std::min(kCopyChunk, bytes - off);
+        host_copy((char *)h->h_stage + off, (const char *)src + off, len);
+        HIP_TRY(h, hipMemcpyAsync((char *)d_dst + off, (char *)h->h_stage + off, len, hipMemcpyHostToDevice, h->stream));
+    }
+    return MFX_OK;
+}
+
+// device rows -> host, returns when `dst` holds them
+int download_rows(mfx_handle *h, float *dst, const float *d_src, size_t count)
+{
+    const size_t bytes = count * sizeof(float);
+    if (bytes < kCopyChunk || is_pinned_host(dst)) {
+        HIP_TRY(h, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return MFX_OK;
+    }
+    if (h->h_out_stage_n < count) {
+        if (h->h_out_stage) (void)hipHostFree(h->h_out_stage);
+        h->h_out_stage = nullptr;
+        h->h_out_stage_n = 0;
+        const size_t want = std::max(count, (size_t)h->cap_rows * h->width);
+        HIP_TRY(h, hipHostMalloc((void **)&h->h_out_stage, want * sizeof(float), hipHostMallocDefault));
+        h->h_out_stage_n = want;
+    }
+    // chunks of the DMA into pinned staging, each followed by an event; the copy out of staging of chunk c runs under
+    // the DMA of chunk c+1
+    const size_t chunk = std::max(kCopyChunk, (bytes / 16 + 4095) & ~(size_t)4095);
+    int n = 0;
+    for (size_t off = 0; off < bytes; off += chunk, ++n) {
+        const size_t len = std::min(chunk, bytes - off);
+        HIP_TRY(h, hipMemcpyAsync((char *)h->h_out_stage + off, (const char *)d_src + off, len, hipMemcpyDeviceToHost, h->stream));
+        if (!h->ev_copy[n]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_copy[n], hipEventDisableTiming));
+        HIP_TRY(h, hipEventRecord(h->ev_copy[n], h->stream));
+    }
+    n = 0;
+    for (size_t off = 0; off < bytes; off += chunk, ++n) {
+        const size_t len = std::min(chunk, bytes - off);
+        HIP_TRY(h, hipEventSynchronize(h->ev_copy[n]));
+        host_copy((char *)dst + off, (const char *)h->h_out_stage + off, len);
+    }
+    return MFX_OK;
+}
+
 int stream_front(mfx_handle *h, int wcnd)
 {
     FrontParams p;
@@ -774,15 +871,18 @@ extern "C" int mfx_set_input(mfx_handle *h, const int16_t *pcm, int32_t samples,
     h->block_frames = 0;
 
     const int D = h->D, W = h->W, S = h->S;
-    // the caller may overwrite `pcm` as soon as we return: stage through pinned memory
+    // the caller may overwrite `pcm` as soon as we return: the block goes through pinned staging (upload_block), whose
+    // previous contents the stream has long consumed (get_output_data / mfx_synchronize waited for it)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    std::memcpy(h->h_stage, pcm, sizeof(int16_t) * (size_t)samples);
+    bool direct = false;
 
     h->last_calc_flushed = h->flushed;
     int window_count = 0, wcnd = 0;
     if (h->last_calc_flushed) {
-        HIP_TRY(h, hipMemcpyAsync(h->d_carry[h->cur].p, h->h_stage, sizeof(int16_t) * (size_t)samples,
-                                  hipMemcpyHostToDevice, h->stream));
+        {
+            int rcu = upload_block(h, h->d_carry[h->cur].p, pcm, (size_t)samples, &direct);
+            if (rcu != MFX_OK) return rcu;
+        }
         wcnd = estimated_window_count_f32(samples, W, S);
         window_count = wcnd - D;
         if (window_count <= 0) return fail(h, MFX_ERR_WINDOW_COUNT, kMsgWindow);
@@ -797,8 +897,10 @@ extern "C" int mfx_set_input(mfx_handle *h, const int16_t *pcm, int32_t samples,
         h->samples = samples;
     } else {
         if ((size_t)samples + (size_t)h->remaining > h->carry_capacity) return fail(h, MFX_ERR_BUFFER_TOO_SMALL, kMsgBuffer);
-        HIP_TRY(h, hipMemcpyAsync(h->d_carry[h->cur].p + h->remaining, h->h_stage, sizeof(int16_t) * (size_t)samples,
-                                  hipMemcpyHostToDevice, h->stream));
+        {
+            int rcu = upload_block(h, h->d_carry[h->cur].p + h->remaining, pcm, (size_t)samples, &direct);
+            if (rcu != MFX_OK) return rcu;
+        }
         const int total = samples + h->remaining;
         wcnd = estimated_window_count_f32(total, W, S);
         window_count = wcnd - 2 * D;
@@ -815,6 +917,7 @@ extern "C" int mfx_set_input(mfx_handle *h, const int16_t *pcm, int32_t samples,
     }
     h->block_frames = window_count;
     *frames_out = window_count;
+    if (direct) HIP_TRY(h, hipEventSynchronize(h->ev_copy[0])); // DMA from the caller's own (pinned) buffer: done before we return
     return MFX_OK;
 }
 
@@ -1063,10 +1166,7 @@ extern "C" int mfx_get_output_data_alpha(mfx_handle *h, int32_t alpha_index, flo
     if (frames > h->cap_rows) return fail(h, MFX_ERR_WINDOW_HIGH, kMsgHigh);
     if (frames == 0) return MFX_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpyAsync(data_out, h->d_sweep_blk.p + (size_t)alpha_index * h->cap_rows * h->width,
-                              sizeof(float) * (size_t)frames * h->width, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return MFX_OK;
+    return download_rows(h, data_out, h->d_sweep_blk.p + (size_t)alpha_index * h->cap_rows * h->width, (size_t)frames * h->width);
 }
 
 extern "C" int mfx_get_output_data(mfx_handle *h, float *data_out, int32_t frames)
@@ -1076,10 +1176,7 @@ extern "C" int mfx_get_output_data(mfx_handle *h, float *data_out, int32_t frame
     if (frames > h->cap_rows) return fail(h, MFX_ERR_WINDOW_HIGH, kMsgHigh);
     if (frames == 0) return MFX_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpyAsync(data_out, h->d_blk.p, sizeof(float) * (size_t)frames * h->width, hipMemcpyDeviceToHost,
-                              h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return MFX_OK;
+    return download_rows(h, data_out, h->d_blk.p, (size_t)frames * h->width);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -12,7 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <atomic>
+#include <charconv>
 #include <future>
 #include <mutex>
 #include <stdexcept>
@@ -138,26 +140,73 @@ void write_htk_header(FILE *f, uint32_t n_frames, const Options &o, int width)
     put_be16(f, (uint16_t)(4 * width));
     put_be16(f, kind);
 }
-void write_rows_htk(FILE *out, const float *rows, int n, int width)
+void write_rows_htk(FILE *out, const float *rows, int n, int width, std::vector<char> &buf)
 {
-    for (size_t i = 0; i < (size_t)n * width; ++i) {
+    const size_t count = (size_t)n * width;
+    buf.resize(count * 4);
+    for (size_t i = 0; i < count; ++i) { // big endian, one write for the block
         uint32_t u;
         std::memcpy(&u, &rows[i], 4);
-        put_be32(out, u);
+        buf[4 * i] = (char)(u >> 24);
+        buf[4 * i + 1] = (char)(u >> 16);
+        buf[4 * i + 2] = (char)(u >> 8);
+        buf[4 * i + 3] = (char)u;
     }
+    std::fwrite(buf.data(), 1, buf.size(), out);
 }
 
-void write_rows(FILE *out, const float *rows, int n, int width, int first_frame, long double t0, long double dt)
+// "%f" of a double into p (std::to_chars with fixed notation and precision 6 is specified to produce what printf("%f")
+// prints in the C locale, i.e. the reference's text, ASR_OCL.cpp:254-257 -- only without a format parse per value)
+inline char *put_f(char *p, char *end, double v)
 {
-    for (int f = 0; f < n; ++f) {
-        std::fprintf(out, "| %f |", (double)(t0 + (first_frame + f) * dt));
-        for (int i = 0; i < width; ++i) std::fprintf(out, " %f |", rows[(size_t)width * f + i]);
-        std::fprintf(out, "\n");
-    }
+    if (!(v == v) || v - v != 0.0) return p + std::snprintf(p, (size_t)(end - p), "%f", v); // nan / inf as printf spells them
+    return std::to_chars(p, end, v, std::chars_format::fixed, 6).ptr;
 }
+
+void write_rows(FILE *out, const float *rows, int n, int width, int first_frame, long double t0, long double dt,
+                std::vector<char> &buf)
+{
+    // a value needs at most 1 + 39 + 1 + 6 characters plus " |"; rows are formatted into one buffer and written once
+    buf.resize((size_t)n * ((size_t)width + 1) * 52 + 16);
+    char *p = buf.data(), *end = buf.data() + buf.size();
+    for (int f = 0; f < n; ++f) {
+        *p++ = '|';
+        *p++ = ' ';
+        p = put_f(p, end, (double)(t0 + (first_frame + f) * dt));
+        *p++ = ' ';
+        *p++ = '|';
+        for (int i = 0; i < width; ++i) {
+            *p++ = ' ';
+            p = put_f(p, end, (double)rows[(size_t)width * f + i]);
+            *p++ = ' ';
+            *p++ = '|';
+        }
+        *p++ = '\n';
+    }
+    std::fwrite(buf.data(), 1, (size_t)(p - buf.data()), out);
+}
+
+// --timing: wall time per phase, summed over the files of all workers (dev aid; printed at exit)
+struct Timing {
+    std::atomic<long long> wait_read{0}, prep{0}, device{0}, write{0}, files{0};
+    bool on = false;
+} g_time;
+inline long long now_ns()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+}
+
+// buffers a worker keeps from file to file (the row buffer alone is ~10 MB at the reference's default sample limit)
+struct Scratch {
+    std::vector<float> rows;
+    std::vector<int16_t> mono;
+    std::vector<char> text;
+};
 
 void process_file(MfccHip &param, const Options &o, const Wav &w, const std::string &in, const std::string &out_name,
-                  float sample_rate)
+                  float sample_rate, Scratch &sc)
 {
     if ((float)w.sample_rate != sample_rate)
         throw std::runtime_error("File \"" + in + "\" has incorrect sample rate");
@@ -165,7 +214,10 @@ void process_file(MfccHip &param, const Options &o, const Wav &w, const std::str
     // ABI: mono = (L + R) >> 1 in integer arithmetic), applied here on the host because the streaming
     // interface is mono like the reference's (which has no downmix at all: it reads `frames` shorts into a mono-sized
     // buffer, ASR_OCL.cpp:229-231).  More than two channels: the first two.
-    std::vector<int16_t> mono(w.pcm.size() / w.channels);
+    const long long t_begin = g_time.on ? now_ns() : 0;
+    long long t_dev = 0, t_wr = 0;
+    std::vector<int16_t> &mono = sc.mono;
+    mono.resize(w.pcm.size() / w.channels);
     for (size_t i = 0; i < mono.size(); ++i)
         mono[i] = w.channels >= 2 ? (int16_t)(((int)w.pcm[i * w.channels] + (int)w.pcm[i * w.channels + 1]) >> 1)
                                   : w.pcm[i * w.channels];
@@ -173,7 +225,8 @@ void process_file(MfccHip &param, const Options &o, const Wav &w, const std::str
     const int limit = param.get_input_buffer_size();
     const int width = param.get_output_data_width();
     const int rows_cap = std::max(param.estimated_window_count(limit), 0) + 64;
-    std::vector<float> rows((size_t)rows_cap * width);
+    std::vector<float> &rows = sc.rows;
+    if (rows.size() < (size_t)rows_cap * width) rows.resize((size_t)rows_cap * width);
     // Frame time column.  The reference divides its window / shift IN MILLISECONDS by the sample rate
     // (ASR_OCL.cpp:225-226: cfg.shift / cfg.sample_rate, 0.5f * cfg.window_size / cfg.sample_rate, float arithmetic):
     // 0.000625 s per frame at 10 ms / 16 kHz instead of 0.01 s.  --bug-compat 1 (default) prints
@@ -199,6 +252,7 @@ void process_file(MfccHip &param, const Options &o, const Wav &w, const std::str
     // the whole sweep over the block's stored spectrum in one call (mfx_apply_alphas).
     auto emit = [&](int n) {
         if (n <= 0) return;
+        long long t0e = g_time.on ? now_ns() : 0;
         if (alphas.size() > 1) param.apply_alphas(alphas.data(), (int)alphas.size());
         for (size_t i = 0; i < outs.size(); ++i) {
             if (alphas.size() > 1) {
@@ -208,20 +262,28 @@ void process_file(MfccHip &param, const Options &o, const Wav &w, const std::str
                 param.apply();
                 param.get_output_data(rows.data(), n);
             }
+            const long long t1e = g_time.on ? now_ns() : 0;
+            t_dev += t1e - t0e;
             if (o.htk)
-                write_rows_htk(outs[i].second, rows.data(), n, width);
+                write_rows_htk(outs[i].second, rows.data(), n, width, sc.text);
             else
-                write_rows(outs[i].second, rows.data(), n, width, total, t0, dt);
+                write_rows(outs[i].second, rows.data(), n, width, total, t0, dt, sc.text);
+            t0e = g_time.on ? now_ns() : 0;
+            t_wr += t0e - t1e;
         }
     };
     while (pos < mono.size()) {
         const int n_in = (int)std::min<size_t>(mono.size() - pos, (size_t)limit);
+        const long long ts0 = g_time.on ? now_ns() : 0;
         const int n = param.set_input(mono.data() + pos, n_in);
+        if (g_time.on) t_dev += now_ns() - ts0;
         emit(n);
         total += n;
         pos += n_in;
     }
+    const long long tf0 = g_time.on ? now_ns() : 0;
     const int n = param.flush();
+    if (g_time.on) t_dev += now_ns() - tf0;
     if (n > 0) emit(n);
     total += n;
     for (auto &oa : outs) {
@@ -230,6 +292,13 @@ void process_file(MfccHip &param, const Options &o, const Wav &w, const std::str
             write_htk_header(oa.second, (uint32_t)total, o, width);
         }
         std::fclose(oa.second);
+    }
+    if (g_time.on) {
+        const long long t_end = now_ns();
+        g_time.device += t_dev;
+        g_time.write += t_wr;
+        g_time.prep += (t_end - t_begin) - t_dev - t_wr; // downmix, opening and closing the outputs
+        ++g_time.files;
     }
     static std::mutex print_lock;
     std::lock_guard<std::mutex> g(print_lock);
@@ -264,12 +333,15 @@ void worker(const Options &o, int device, float sr, const std::vector<std::strin
             return true;
         };
         Pending cur, nxt;
+        Scratch sc;
         bool have = claim(cur);
         while (have) {
             const bool have_next = claim(nxt);
             try {
+                const long long tw0 = g_time.on ? now_ns() : 0;
                 const Wav w = cur.wav.get();
-                process_file(param, o, w, files[2 * cur.i], files[2 * cur.i + 1], sr);
+                if (g_time.on) g_time.wait_read += now_ns() - tw0;
+                process_file(param, o, w, files[2 * cur.i], files[2 * cur.i + 1], sr, sc);
             } catch (const std::exception &e) { // a bad file does not stop the queue
                 std::fprintf(stderr, "Exception caught %s\n", e.what());
                 ++failures;
@@ -326,6 +398,7 @@ int main(int argc, char **argv)
         }
         else if (a == "--bug-compat") o.bug_compat = std::atoi(val()) != 0;
         else if (a == "--htk") o.htk = true;
+        else if (a == "--timing") g_time.on = true;
         else if (a == "--help") {
             std::printf("afet_hip [--window-size ms] [--shift ms] [--banks n] [--ceps n] [--c0 0|1] [--norm 0..3]\n"
                         "         [--dyn 0..2] [--l1 n] [--l2 n] [--low-freq hz] [--high-freq hz] [--lift-coef x]\n"
@@ -353,6 +426,12 @@ int main(int argc, char **argv)
             std::vector<std::thread> pool;
             for (int d : o.devices) pool.emplace_back(worker, std::cref(o), d, sr, std::cref(files), std::ref(next), std::ref(failures));
             for (auto &t : pool) t.join();
+        }
+        if (g_time.on && g_time.files > 0) {
+            const double n = (double)g_time.files.load();
+            std::fprintf(stderr, "timing per file (us): waiting for the reader %.0f, host preparation %.0f, device calls %.0f, "
+                                 "formatting + writing %.0f\n", g_time.wait_read / n / 1e3, g_time.prep / n / 1e3,
+                         g_time.device / n / 1e3, g_time.write / n / 1e3);
         }
         return failures.load() ? 1 : 0;
     } catch (const std::exception &e) {
