@@ -12,4 +12,18 @@ done
 for f in bench_C2_default bench_C2_steps20_warmup5 bench_C3 bench_C5 bench_C4 bench_C2_gpus2_one_device_gloo; do
   [ -f "$T/$f.json" ] && cp "$T/$f.json" "$D/${P}_$f.json"
 done
+for f in stream_bench afet_bench; do [ -f "$T/$f.txt" ] && cp "$T/$f.txt" "$D/${P}_$f.txt"; done
+# HBM traffic per workload for bench.py's roofline.traffic (labelled there as read from this file)
+python3 - "$R/profiles/traffic_latest.json" "$T" <<'PY'
+import json, os, sys
+path, t = sys.argv[1:3]
+cur = {}
+for wl in ("C2", "C3", "C5"):
+    f = os.path.join(t, "pmc_" + wl, "traffic.json")
+    if os.path.exists(f):
+        e = json.load(open(f)); e["workload"] = wl
+        e["source"] = "rocprofv3 --pmc passes (tools/pmc_run.sh): FETCH_SIZE x2 + WRITE_SIZE, KiB, per launch of the front-end kernel"
+        cur[wl] = e
+if cur: json.dump(cur, open(path, "w"), indent=1, sort_keys=True)
+PY
 ls "$D" | grep "^$P" | wc -l
