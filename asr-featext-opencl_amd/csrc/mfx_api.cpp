@@ -215,7 +215,7 @@ int refresh_mel(mfx_handle *h)
     }
     h->wplan_ok = false;
     if (h->W2 >= 1024 && h->W2 <= 2048) { // the fused long-transform kernel walks the filters on the frame's 64 lanes
-        const int M = h->W2 / 2, MP = M + (M >> (h->W2 == 1024 ? 3 : 4));
+        const int M = h->W2 / 2, MP = M; // floats of the wave's complex buffer = 2 MP (k_front_reg)
         if (build_mel_wave_plan(t, h->nb, h->W2, /*max_read_bin=*/2 * MP - 1, h->wplan)) {
             HIP_TRY(h, upload(h->d_mel64_w, h->wplan.w));
             HIP_TRY(h, upload(h->d_mel64_start, h->wplan.start));

@@ -8,6 +8,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 namespace mfx {
 
 namespace {
@@ -230,7 +232,10 @@ __device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int
 // 0) one iteration ahead of its use.
 // ------------------------------------------------------------------------------------------------
 constexpr int kSlot = 512;    // dwords per frame slot
-constexpr int kWaves = 16;    // waves per block of the 512-point kernel (one block per CU)
+#ifndef MFX_WAVES512
+#define MFX_WAVES512 16
+#endif
+constexpr int kWaves = MFX_WAVES512;    // waves per block of the 512-point kernel (16 waves per CU in all)
 constexpr int kThreads = kWaves * 64;
 constexpr int kMelOff = 304;  // mel scratch offset inside the slot (after 32 + 257 magnitudes)
 constexpr int kTabStride = 36;   // dwords per lane row of the window / pass-twiddle tables in LDS (16 complex + pad)
@@ -548,7 +553,7 @@ __device__ __forceinline__ void delta_tile16(const Segment &sg, int r0, int rows
 }
 
 template <bool ALIGNED, bool TO_SPEC, int NM, bool FUSE>
-__global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p)
+__global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 waves per SIMD whatever the block size)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -1319,13 +1324,20 @@ __device__ __forceinline__ void fft_r(float2 (&v)[R])
 // One Stockham pass of radix R over the M points in `buf` (in place: all reads, then all writes), sub-transform
 // length LEN before the pass, stride ST = M / LEN.  NB = butterflies per lane.  `v` in/out: with FROM_REGS the
 // inputs are already in v (pass 1), otherwise they are read from buf.
-// Padded LDS layout of the complex buffer: one empty slot after every 2^LP points.  The first pass writes
-// R consecutive points per lane (lane stride R * 8 bytes: without the pad all lanes of an access fall on the
-// same bank pair, a 32-way conflict); with it the stride is odd in 8-byte slots.
+// Index of point i in the wave's complex LDS buffer (LP = 3: radix-8 passes, LP = 4: radix-16 passes).
 template <int LP>
 __device__ __forceinline__ int pad_idx(int i)
 {
+#ifdef MFX_REG_PADDED
     return i + (i >> LP);
+#else
+    // XOR swizzle of the complex buffer (no padding): the strided writes of the first pass (R consecutive points per
+    // lane: without it all 16 lanes of a write group fall on one bank pair) spread over the banks, and every run of 16 /
+    // 32 consecutive points -- the later passes' and the real split's accesses -- stays a permutation inside its own
+    // 16-point block.  Simulated against the LDS access rules for all passes (8.8.8 / 16.16.4 / 16.16.8): 152 / 304 / 608
+    // LDS cycles per transform against 224 / 384 / 768 with the padded layout of round 1 (144 / 288 / 576 conflict free).
+    return LP == 3 ? (i ^ ((i >> 4) & 7) ^ (((i >> 6) & 1) << 3)) : (i ^ ((i >> 4) & 15));
+#endif
 }
 
 // s_tw: this pass's twiddles W_LEN^(pp k) laid out [k - 1][pp], pp < LEN / R (unused by the last pass)
@@ -1364,7 +1376,11 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
 {
     constexpr int M = 1 << LOG2M, NV = M / 64;
     constexpr int R1 = (LOG2M == 9) ? 8 : 16, R2 = R1, R3 = M / (R1 * R2);
+#ifdef MFX_REG_PADDED
     constexpr int LP = (LOG2M == 9) ? 3 : 4, MP = M + (M >> LP); // padded buffer (pad_idx)
+#else
+    constexpr int LP = (LOG2M == 9) ? 3 : 4, MP = M;             // swizzled buffer (pad_idx)
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
     const int nb = p.num_banks, dl = p.dct_len;
@@ -2003,7 +2019,11 @@ size_t front_reg_lds_floats(const FrontParams &p, bool fused, int n_waves)
     const size_t M = (size_t)p.fft_size >> 1;
     size_t f = 2 * M + 2 * (M / 2 + 2) + 2 * M; // pass twiddles, split twiddles, window pairs
     if (fused) f += (size_t)64 * p.mel64_row_stride + (size_t)128 * p.mel64_rounds; // lane weight rows, starts + filter ids
+#ifdef MFX_REG_PADDED
     const size_t MP = M + (M >> (p.fft_size == 1024 ? 3 : 4)); // padded buffer (pad_idx)
+#else
+    const size_t MP = M;
+#endif
     f += (size_t)n_waves * (2 * MP + (fused ? 4 * lm_stride(p.num_banks) : 0));
     return f;
 }
@@ -2014,9 +2034,25 @@ int front_reg_waves(const FrontParams &p, bool fused)
     // (4096 points: 4 waves -- the kernel is built for 256 threads there, its 32 points per lane need the registers)
     // (2048 points fused: 8 waves -- its tables leave no room for more, and the build allows 256 registers there)
     const int top = p.fft_size >= 4096 ? 4 : (p.fft_size == 2048 && fused) ? MFX_REG10_THREADS / 64 : 16;
-    for (int nw = top; nw >= 4; nw = nw > 8 ? nw - 2 : nw >> 1)
-        if (front_reg_lds_floats(p, fused, nw) * sizeof(float) <= 160 * 1024) return nw;
-    return 0;
+    // The block size that puts most waves on a CU (every block carries its own copy of the tables).  1024 points: at
+    // 16 waves per CU two blocks of 8 beat one block of 16 (C3: 0.368 against 0.418 ms; 4 x 4: 0.431, 2 x 9 and 1 x 10
+    // do not fit twice and lose) -- blocks that run out of step with each other spread their LDS phases.
+    int best = 0, best_total = 0;
+    for (int nw = top; nw >= 4; --nw) {
+        const size_t lds = front_reg_lds_floats(p, fused, nw) * sizeof(float);
+        if (lds > 160 * 1024) continue;
+        int per_cu = p.fft_size == 1024 ? (int)((160 * 1024) / lds) : 1;
+        if (per_cu * nw > 16) per_cu = 16 / nw;
+        if (per_cu < 1) continue;
+        const int total = per_cu * nw;
+        if (total > best_total || (total == best_total && p.fft_size == 1024 && nw >= 8)) {
+            best_total = total;
+            best = nw;
+        }
+    }
+    const char *e = std::getenv("MFX_REG_NW"); // dev override
+    if (e && std::atoi(e) >= 4 && std::atoi(e) <= top) best = std::atoi(e);
+    return best;
 }
 
 template <int LOG2M, bool FUSED, bool PAIR, bool HALF>
@@ -2036,7 +2072,8 @@ hipError_t launch_reg(const FrontParams &p, int nw, hipStream_t stream)
 {
     const size_t lds = front_reg_lds_floats(p, FUSED, nw) * sizeof(float);
     int blocks = (p.n_chunks + nw - 1) / nw;
-    const int cap = num_cus() * (lds * 2 <= 160 * 1024 && nw <= 16 ? 2 : 1);
+    const int per_cu = (int)((160 * 1024) / lds);
+    const int cap = num_cus() * (per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu);
     if (blocks > cap) blocks = cap;
     // the half-window build exists for 1024 points only (25 ms at 16 kHz zero padded to 1024: BASELINE configs[2])
     if (LOG2M == 9 && p.window_size <= (1 << LOG2M)) {
