@@ -1286,6 +1286,14 @@ __host__ __device__ inline int lm_stride(int nb)
 #define MFX_REG10_THREADS 512   // threads per block of the fused 2048-point build (sets its register budget)
 #endif
 
+// window pairs k_front_reg keeps in LDS: the 64-pair rows that carry taps (a 25 ms window zero padded to the transform
+// leaves most of the M rows empty)
+__host__ __device__ inline int reg_window_pairs(int window_size, int M)
+{
+    const int n = (((window_size + 1) / 2) + 63) & ~63;
+    return n < M ? n : M;
+}
+
 // 8-point forward DFT in registers, natural order in and out
 __device__ __forceinline__ void fft8(float2 (&x)[8])
 {
@@ -1388,11 +1396,12 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
     constexpr int NT1 = (R1 - 1) * (M / R1), NT2 = (R2 - 1) * (M / (R1 * R2));
     float2 *s_tw = (float2 *)smem;                 // pass 1 [R1-1][M/R1], then pass 2 [R2-1][M/(R1 R2)]; M slots reserved
     float2 *s_cs = s_tw + M;                       // [M/2 + 1]  -i W_{2M}^k (one per bin pair), padded to even
-    float2 *s_win = s_cs + (M / 2 + 2);            // [M]   (w[2n], w[2n+1]) * 0.5 / W2
+    float2 *s_win = s_cs + (M / 2 + 2);            // [nwin] (w[2n], w[2n+1]) * 0.5 / W2: whole 64-pair rows that carry taps
+    const int nwin = reg_window_pairs(p.window_size, M);
     // FUSED: the mel walk's per-lane weight rows and plan (MelWavePlan), then per wave the complex buffer and the
     // log mel energies of 4 frames (the DCT runs on the matrix pipe once per 4 frames)
     const int RS = FUSED ? p.mel64_row_stride : 0, rounds = FUSED ? p.mel64_rounds : 0;
-    float *s_mw = (float *)(s_win + M);                        // [64][RS]
+    float *s_mw = (float *)(s_win + nwin);                     // [64][RS]
     int *s_mst = (int *)(s_mw + 64 * RS);                      // [rounds][64]
     int *s_mfid = s_mst + 64 * rounds;                         // [rounds][64]
     const int nbp = FUSED ? lm_stride(nb) : 0;
@@ -1405,8 +1414,10 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
     static_assert(NT1 + NT2 <= M, "pass tables fit the reserved slots");
     for (int i = tid; i < M; i += blockDim.x) {
         if (i < NT1 + NT2) s_tw[i] = ((const float2 *)p.twid_reg)[i];
-        const float2 wv = ((const float2 *)p.window)[i];
-        s_win[i] = make_float2(wv.x * scale, wv.y * scale);
+        if (i < nwin) {
+            const float2 wv = ((const float2 *)p.window)[i];
+            s_win[i] = make_float2(wv.x * scale, wv.y * scale);
+        }
     }
     for (int i = tid; i <= M / 2; i += blockDim.x) s_cs[i] = ((const float2 *)p.twid_split)[i];
     if (FUSED) {
@@ -1464,7 +1475,7 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
                         if (has1) x1 = (float)((int)d >> 16);
                     }
                 }
-                const float2 w = s_win[n];
+                const float2 w = 64 * j < nwin ? s_win[n] : make_float2(0.f, 0.f); // (rows past the window: no table)
                 v[j] = make_float2(w.x * x0, w.y * x1);
             }
             // Pass 1 wants, per butterfly b, its R1 inputs z[pp + (M/R1) r] contiguous in v: with NB1 = M/R1/64
@@ -2017,7 +2028,7 @@ bool use_front_reg(const FrontParams &p) { return p.fft_size == 1024 || p.fft_si
 size_t front_reg_lds_floats(const FrontParams &p, bool fused, int n_waves)
 {
     const size_t M = (size_t)p.fft_size >> 1;
-    size_t f = 2 * M + 2 * (M / 2 + 2) + 2 * M; // pass twiddles, split twiddles, window pairs
+    size_t f = 2 * M + 2 * (M / 2 + 2) + 2 * (size_t)reg_window_pairs(p.window_size, (int)M); // pass twiddles, split twiddles, window pairs
     if (fused) f += (size_t)64 * p.mel64_row_stride + (size_t)128 * p.mel64_rounds; // lane weight rows, starts + filter ids
 #ifdef MFX_REG_PADDED
     const size_t MP = M + (M >> (p.fft_size == 1024 ? 3 : 4)); // padded buffer (pad_idx)
@@ -2041,11 +2052,12 @@ int front_reg_waves(const FrontParams &p, bool fused)
     for (int nw = top; nw >= 4; --nw) {
         const size_t lds = front_reg_lds_floats(p, fused, nw) * sizeof(float);
         if (lds > 160 * 1024) continue;
-        int per_cu = p.fft_size == 1024 ? (int)((160 * 1024) / lds) : 1;
-        if (per_cu * nw > 16) per_cu = 16 / nw;
+        const int cu_waves = p.fft_size == 2048 ? 8 : 16; // (2048 points: 190 registers -> 2 waves per SIMD)
+        int per_cu = p.fft_size <= 2048 ? (int)((160 * 1024) / lds) : 1;
+        if (per_cu * nw > cu_waves) per_cu = cu_waves / nw;
         if (per_cu < 1) continue;
         const int total = per_cu * nw;
-        if (total > best_total || (total == best_total && p.fft_size == 1024 && nw >= 8)) {
+        if (total > best_total || (total == best_total && p.fft_size <= 2048 && nw >= cu_waves / 2)) {
             best_total = total;
             best = nw;
         }
