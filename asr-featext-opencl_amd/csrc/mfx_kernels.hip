@@ -574,8 +574,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
     float *s_melw = s_split + 16 * kSplitStride;     // [16][RS]
     int *s_mstart = (int *)(s_melw + 16 * RS);       // [rounds][16]
     int *s_mfid = s_mstart + 16 * rounds;            // [rounds][16]
-    int *s_mplan = s_mfid + 16 * rounds;             // [16][4] per-lane plan of the unrolled mel walk (dct_mode 1)
-    float *s_dct = (float *)(s_mplan + 64);          // [cols][DS]
+    float *s_dct = (float *)(s_mfid + 16 * rounds);  // [cols][DS]
     // dct_mode 0: transposed matrix [cols][DS]; dct_mode 1: matrix-pipe B operands per lane, [64][kDctRow]
     const int dct_floats = !p.dct ? 0 : p.dct_mode == 1 ? 64 * kDctRow : cols * DS;
     float *s_wave = s_dct + dct_floats + wave * (4 * kSlot);
@@ -602,19 +601,6 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
             s_mstart[i] = p.mel_lane_start[i];
             s_mfid[i] = p.mel_lane_fid[i];
         }
-        if (p.dct_mode == 1 && tid < 16) {
-            // plan of the unrolled mel walk: byte offset of round 0's first bin, the steps of that offset where the
-            // walk changes round (a trip t reads at offset + 32 t), and the three filter ids (idle: a word nobody reads)
-            auto st = [&](int r) { return r < rounds ? p.mel_lane_start[r * 16 + tid] : 0; };
-            auto fx = [&](int r) {
-                const int f = r < rounds ? p.mel_lane_fid[r * 16 + tid] : -1;
-                return f >= 0 ? f : 4 * kDctSteps;
-            };
-            s_mplan[4 * tid + 0] = 4 * st(0);
-            s_mplan[4 * tid + 1] = 4 * (st(1) - st(0)) - 4 * p.mel_L[0];
-            s_mplan[4 * tid + 2] = 4 * (st(2) - st(1)) - 4 * p.mel_L[1];
-            s_mplan[4 * tid + 3] = fx(0) | (fx(1) << 8) | (fx(2) << 16);
-        }
         if (p.dct_mode == 1) {
             // B operand of K step j on lane (k = lane >> 4, n = lane & 15) is dct[4 j + k][n]; zeros beyond the matrix
             for (int i = tid; i < 64 * kDctRow; i += kThreads) {
@@ -628,10 +614,6 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
     // the slots are read (times zero weights) before every word has been written once: make them finite
     for (int i = lane; i < 4 * kSlot; i += 64) s_wave[i] = 0.f;
     __syncthreads();
-    // Unrolled mel walk (dct_mode 1): at most 3 rounds and 8 trips of 8 bins in all.  mE* = trip at which a round ends.
-    const int mE0 = rounds > 0 ? p.mel_L[0] >> 3 : 0, mE1 = mE0 + (rounds > 1 ? p.mel_L[1] >> 3 : 0),
-              mE2 = mE1 + (rounds > 2 ? p.mel_L[2] >> 3 : 0);
-    const bool mel_fast = !TO_SPEC && p.dct_mode == 1 && rounds >= 1 && rounds <= 3 && mE2 <= 8;
 
     // ---- FUSE: the delta wave.  It consumes the block's tiles in order; a tile is ready once the
     // chunks it reads (its own rows and up to D rows either side) have their bits set in s_done.  The
@@ -930,8 +912,6 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
                     for (int pp = 0; pp < 8; ++pp) mhi[16 * pp] = mag_p[7 - pp];
                     if (l == 0) mg0[128] = mag128;
                 }
-                int4 mplan = make_int4(0, 0, 0, 0);
-                if (p.dct_mode == 1) mplan = *(const int4 *)(s_mplan + 4 * l);
                 wave_sync();
 
                 // ---- mel filterbank: per round every lane walks one filter's bins in ascending
@@ -950,58 +930,6 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
                     // copies: all 64 lanes read valid energies), so register 0 of the result is out[slot][c] on
                     // lane (slot, c) -- exactly the lane that stores it.
                     float *lm = xb + kMelOff + 8 * slot;
-                    if (mel_fast) {
-                        // the walk, fully unrolled and software pipelined: trip t + 1's six LDS reads are in flight during
-                        // trip t's eight multiply-adds; a round's end is a scalar branch (log, store, restart the sum)
-                        struct Trip {
-                            float4 w0, w1;
-                            float2 m[4];
-                        };
-                        const char *wb = (const char *)wrow;
-                        int mo = mplan.x;
-                        // (the round ends are re-read here so that the comparisons below are made where they are used:
-                        // hoisted out of the chunk loop they cost more scalar registers than there are)
-                        int e0 = mE0, e1 = mE1, e2 = mE2;
-                        asm volatile("" : "+s"(e0), "+s"(e1), "+s"(e2));
-                        auto issue = [&](Trip &T, int t) {
-                            const float4 *wp = (const float4 *)(wb + 32 * t);
-                            const float2 *mp = (const float2 *)((const char *)mg0 + mo + 32 * t);
-                            T.w0 = lds_read_b128(wp);
-                            T.w1 = lds_read_b128(wp + 1);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) T.m[q] = lds_read_b64(mp + q);
-                        };
-                        Trip tA, tB;
-                        float acc = 0.f;
-                        issue(tA, 0);
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) {
-                            if (t < e2) {
-                                Trip &cur = (t & 1) ? tB : tA;
-                                Trip &nxt = (t & 1) ? tA : tB;
-                                if (t + 1 < e2) {
-                                    if (t + 1 == e0)
-                                        mo += mplan.y;
-                                    else if (t + 1 == e1)
-                                        mo += mplan.z;
-                                    issue(nxt, t + 1);
-                                }
-                                acc += cur.w0.x * cur.m[0].x;
-                                acc += cur.w0.y * cur.m[0].y;
-                                acc += cur.w0.z * cur.m[1].x;
-                                acc += cur.w0.w * cur.m[1].y;
-                                acc += cur.w1.x * cur.m[2].x;
-                                acc += cur.w1.y * cur.m[2].y;
-                                acc += cur.w1.z * cur.m[3].x;
-                                acc += cur.w1.w * cur.m[3].y;
-                                if (t + 1 == e0 || t + 1 == e1 || t + 1 == e2) {
-                                    const int fid = t + 1 == e0 ? (mplan.w & 255) : t + 1 == e1 ? ((mplan.w >> 8) & 255) : (mplan.w >> 16);
-                                    lm[fid] = MFX_LOG(fmaxf(acc, 1e-30f));
-                                    acc = 0.f;
-                                }
-                            }
-                        }
-                    } else
                     for (int r = 0; r < rounds; ++r) {
                         const int L = p.mel_L[r];
                         const float *mg = mg0 + s_mstart[r * 16 + l];
@@ -1928,7 +1856,7 @@ size_t front512_lds_bytes(const FrontParams &p)
 {
     size_t f = 2 * 16 * kTabStride + 16 * kSplitStride;  // window pairs, pass twiddles, split twiddles
     f += (size_t)16 * p.mel_row_stride;                  // per-lane mel weights
-    f += (size_t)32 * p.mel_rounds + 64;                 // per-lane bin starts + filter ids, plan of the unrolled walk
+    f += (size_t)32 * p.mel_rounds;                      // per-lane bin starts + filter ids
     f += !p.dct ? 0 : p.dct_mode == 1 ? (size_t)64 * kDctRow : (size_t)p.cols * p.dct_stride; // DCT table (either form)
     f += kWaves * 4 * kSlot;                             // 4 frame slots per wave
     f += 4;                                              // block-local work counter
