@@ -241,14 +241,6 @@ constexpr int kMelOff = 304;  // mel scratch offset inside the slot (after 32 + 
 constexpr int kTabStride = 36;   // dwords per lane row of the window / pass-twiddle tables in LDS (16 complex + pad)
 constexpr int kSplitStride = 20; // dwords per lane row of the split-twiddle table (8 complex + pad)
 
-// y[l] = x[(16 - l) & 15] inside every row of 16 lanes: mirror, then rotate right by one
-__device__ __forceinline__ float row_partner(float x)
-{
-    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, true); // row_mirror
-    t = __builtin_amdgcn_update_dpp(0, t, 0x121, 0xf, 0xf, true);                      // row_ror:1
-    return __int_as_float(t);
-}
-
 // DCT on the matrix pipe (dct_mode 1): K steps of v_mfma_f32_16x16x4_f32 over the mel bands, 4 bands per step
 constexpr int kDctSteps = 10;  // num_banks <= 40
 constexpr int kDctRow = 12;    // dwords per lane row of the B operand table in LDS (16-byte words, disjoint bank quads)
