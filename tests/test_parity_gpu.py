@@ -877,6 +877,41 @@ def test_random_configuration(pkg, orc, case):
     assert_close(m.batch_run_host(pcm), orc.run_utterance(cfg, pcm, w, bug_compat=False), "batch", groups=g)
 
 
+@pytest.mark.parametrize("case", _random_cases(40, 77770002)[24:], ids=lambda c: "fft%d_W%d_S%d_nb%d_nc%d_dyn%d" % (
+    c["fft"], c["W"], c["S"], c["nb"], c["nc"], c["dyn"]))
+def test_random_ragged_batches(pkg, orc, case):
+    """Random configurations (second seed) through the BATCH entry with several utterances of ragged lengths packed
+    back to back at arbitrary (odd and even) offsets -- utterances that end exactly on the array's last sample, that
+    hold exactly one frame, 2D frames, 2D + 1 frames: every utterance against the oracle fed that utterance alone."""
+    c = case
+    rng = np.random.default_rng(c["seed"])
+    W, S = c["W"], c["S"]
+    D = (c["l1"] + (c["l2"] if c["dyn"] == 2 else 0)) if c["dyn"] else 0
+    frames = [1, 2 * D + 1, 2 * D + 2, 37, 16, 65, int(rng.integers(20, 120))]
+    lens = [(T - 1) * S + W + int(rng.integers(0, S)) for T in frames]
+    lens[-1] = (frames[-1] - 1) * S + W                    # the last one ends exactly on its last sample
+    offs, pos = [], int(rng.integers(0, 3))
+    for n in lens:
+        offs.append(pos)
+        pos += n + int(rng.integers(0, 4))
+    pos = offs[-1] + lens[-1]                              # ... which is the array's last element
+    pcm = np.zeros(pos, np.int16)
+    utts = [synth_utterance(n, c["seed"] + 31 * i, sr=c["sr"]) for i, n in enumerate(lens)]
+    for o_, u in zip(offs, utts):
+        pcm[o_:o_ + u.size] = u
+    m, cfg, w = make_pair(pkg, orc, max(lens) + 1000, W=W, S=S, nb=c["nb"], sr=c["sr"], low=c["low"], high=c["high"],
+                          nc=c["nc"], c0=c["c0"], norm=0, dyn=c["dyn"], l1=c["l1"], l2=c["l2"])
+    rows, total = m.batch_plan(offs, lens)
+    got = m.batch_run_host(pcm)
+    assert total == sum(frames) and got.shape[0] == total
+    g = groups_of(c["dyn"])
+    for i, (T, u) in enumerate(zip(frames, utts)):
+        if T < 2 * D + 1 or T <= D:
+            continue      # shorter than the reference's streaming protocol can express (test_c2_ragged_batch covers those)
+        want = orc.run_utterance(cfg, u, w, bug_compat=False)
+        assert_close(got[rows[i]:rows[i] + T], want, "utterance %d (%d frames)" % (i, T), groups=g)
+
+
 def test_last_frame_ends_on_an_odd_last_sample(pkg, orc):
     """An utterance with an ODD number of samples whose last frame ends exactly on the last sample, at the very end of
     the PCM array: the last sample lies in a 32-bit word that is half past the end.  (Found by the widened random
