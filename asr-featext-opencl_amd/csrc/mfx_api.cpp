@@ -1746,6 +1746,61 @@ extern "C" int mfx_host_mel_item_plan(int32_t num_banks, int32_t fft_size, const
     return plan.K;
 }
 
+// Lane plan of the mel walk (lanes = 16: the 512-point kernel's MelLanePlan, max_read_bin 479; lanes = 64: the
+// long-transform kernel's MelWavePlan).  Returns the number of rounds (<= 8), or an error.  Outputs (any may be NULL to
+// query): L[8] bins per lane and round, *row_stride, start / fid [rounds][lanes], w [lanes][row_stride].
+extern "C" int mfx_host_mel_lane_plan(int32_t lanes, int32_t num_banks, int32_t fft_size, const float *weights,
+                                      const int32_t *beg, int32_t max_read_bin, int32_t *L, int32_t *row_stride,
+                                      int32_t *start, int32_t *fid, float *w, int64_t w_cap)
+{
+    if ((lanes != 16 && lanes != 64) || num_banks <= 0 || fft_size <= 0 || !weights || !beg) return MFX_ERR_ARG;
+    MelTable t;
+    t.weights.assign(weights, weights + (size_t)2 * fft_size);
+    t.beg.assign(beg, beg + num_banks + 2);
+    for (int v : t.beg)
+        if (v < 0 || v > fft_size / 2) return MFX_ERR_ARG;
+    int rounds = 0, rs = 0;
+    const int *Ls = nullptr;
+    const std::vector<int32_t> *st = nullptr, *fd = nullptr;
+    const std::vector<float> *ww = nullptr;
+    MelLanePlan p16;
+    MelWavePlan p64;
+    if (lanes == 16) {
+        if (!build_mel_lane_plan(t, num_banks, fft_size, max_read_bin, p16)) return MFX_ERR_CONFIG;
+        rounds = p16.rounds, rs = p16.row_stride, Ls = p16.L, st = &p16.start, fd = &p16.fid, ww = &p16.w;
+    } else {
+        if (!build_mel_wave_plan(t, num_banks, fft_size, max_read_bin, p64)) return MFX_ERR_CONFIG;
+        rounds = p64.rounds, rs = p64.row_stride, Ls = p64.L, st = &p64.start, fd = &p64.fid, ww = &p64.w;
+    }
+    if (L) std::memcpy(L, Ls, sizeof(int32_t) * 8);
+    if (row_stride) *row_stride = rs;
+    if (start) std::memcpy(start, st->data(), sizeof(int32_t) * st->size());
+    if (fid) std::memcpy(fid, fd->data(), sizeof(int32_t) * fd->size());
+    if (w) {
+        if ((int64_t)ww->size() > w_cap) return MFX_ERR_ARG;
+        std::memcpy(w, ww->data(), sizeof(float) * ww->size());
+    }
+    return rounds;
+}
+
+// Operands of the DCT on the matrix pipe: out[(tile * ksteps + j) * 64 + lane] (build_dct_mfma_operands); returns
+// tiles * ksteps * 64, or the size needed when out is NULL.
+extern "C" int64_t mfx_host_dct_mfma_operands(int32_t num_banks, int32_t dct_len, const float *matrix, float *out,
+                                              int64_t out_cap, int32_t *tiles, int32_t *ksteps)
+{
+    if (num_banks <= 0 || dct_len <= 0 || !matrix) return MFX_ERR_ARG;
+    std::vector<float> m(matrix, matrix + (size_t)num_banks * dct_len), ob;
+    int tl = 0, ks = 0;
+    build_dct_mfma_operands(m, num_banks, dct_len, tl, ks, ob);
+    if (tiles) *tiles = tl;
+    if (ksteps) *ksteps = ks;
+    if (out) {
+        if ((int64_t)ob.size() > out_cap) return MFX_ERR_ARG;
+        std::memcpy(out, ob.data(), sizeof(float) * ob.size());
+    }
+    return (int64_t)ob.size();
+}
+
 extern "C" int mfx_host_dct_matrix(int32_t num_banks, int32_t ceps_len, int32_t want_c0, float lift_coef,
                                    float *matrix)
 {

@@ -54,7 +54,8 @@ EXPORTED_SYMBOLS = (
     "mfx_create", "mfx_destroy", "mfx_last_error", "mfx_status_string", "mfx_abi_version",
     "mfx_set_window", "mfx_set_input", "mfx_flush", "mfx_set_alpha", "mfx_apply",
     "mfx_get_output_data_width", "mfx_get_output_data", "mfx_get_input_buffer_size",
-    "mfx_apply_alphas", "mfx_get_output_data_alpha", "mfx_host_mel_item_plan",
+    "mfx_apply_alphas", "mfx_get_output_data_alpha", "mfx_host_mel_item_plan", "mfx_host_mel_lane_plan",
+    "mfx_host_dct_mfma_operands",
     "mfx_estimated_window_count", "mfx_max_frames_out", "mfx_fft_size",
     "mfx_batch_frames", "mfx_batch_plan", "mfx_batch_run_device", "mfx_batch_run_host", "mfx_batch_overlap",
     "mfx_set_stream", "mfx_synchronize", "mfx_profile_enable", "mfx_profile_read",
@@ -139,6 +140,48 @@ def host_mel_table(num_banks, fft_size, sample_rate, low_freq, high_freq, alpha=
     if rc != 0:
         raise MfxError(rc, "mfx_host_mel_table failed")
     return w, beg
+
+
+def host_mel_lane_plan(lanes, weights, beg, max_read_bin):
+    """Lane plan of the fused kernels' mel walk (lanes = 16 or 64): dict(rounds, L, row_stride, start, fid, w)."""
+    L = load_library()
+    weights = np.ascontiguousarray(weights, dtype=np.float32)
+    beg = np.ascontiguousarray(beg, dtype=np.int32)
+    nb, fft = beg.size - 2, weights.shape[1]
+    ip, fpt = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    fn = L.mfx_host_mel_lane_plan
+    fn.argtypes = [C.c_int32, C.c_int32, C.c_int32, fpt, ip, C.c_int32, ip, ip, ip, ip, fpt, C.c_int64]
+    fn.restype = C.c_int
+    Ls = np.zeros(8, np.int32)
+    rs = C.c_int32(0)
+    rounds = fn(lanes, nb, fft, weights.ctypes.data_as(fpt), beg.ctypes.data_as(ip), int(max_read_bin),
+                Ls.ctypes.data_as(ip), C.byref(rs), None, None, None, 0)
+    if rounds < 0:
+        raise MfxError(rounds, "mfx_host_mel_lane_plan failed")
+    start = np.zeros((rounds, lanes), np.int32)
+    fid = np.zeros((rounds, lanes), np.int32)
+    w = np.zeros((lanes, rs.value), np.float32)
+    rc = fn(lanes, nb, fft, weights.ctypes.data_as(fpt), beg.ctypes.data_as(ip), int(max_read_bin), Ls.ctypes.data_as(ip),
+            C.byref(rs), start.ctypes.data_as(ip), fid.ctypes.data_as(ip), w.ctypes.data_as(fpt), w.size)
+    if rc != rounds:
+        raise MfxError(rc, "mfx_host_mel_lane_plan failed")
+    return dict(rounds=rounds, L=Ls[:rounds].copy(), row_stride=rs.value, start=start, fid=fid, w=w)
+
+
+def host_dct_mfma_operands(matrix):
+    """[tile][K step][64] operands of the DCT on the matrix pipe for a [num_banks][dct_len] matrix."""
+    L = load_library()
+    m = np.ascontiguousarray(matrix, dtype=np.float32)
+    nb, dl = m.shape
+    fpt = C.POINTER(C.c_float)
+    fn = L.mfx_host_dct_mfma_operands
+    fn.argtypes = [C.c_int32, C.c_int32, fpt, fpt, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    fn.restype = C.c_int64
+    tl, ks = C.c_int32(0), C.c_int32(0)
+    n = fn(nb, dl, m.ctypes.data_as(fpt), None, 0, C.byref(tl), C.byref(ks))
+    out = np.zeros(n, np.float32)
+    fn(nb, dl, m.ctypes.data_as(fpt), out.ctypes.data_as(fpt), out.size, C.byref(tl), C.byref(ks))
+    return out.reshape(tl.value, ks.value, 64)
 
 
 def host_mel_item_plan(weights, beg):

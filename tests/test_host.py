@@ -132,6 +132,70 @@ def test_mel_item_plan_covers_every_bin_once(pkg, nb, W2, sr, alpha):
     assert loads.max() <= loads.sum() / 64 + longest + 8
 
 
+@pytest.mark.parametrize("lanes,nb,W2,sr,alpha,max_read", [
+    (16, 40, 512, 16000.0, 1.0, 479), (16, 26, 512, 16000.0, 0.88, 479), (16, 15, 512, 16000.0, 1.12, 479),
+    (64, 80, 1024, 16000.0, 1.0, 1023), (64, 128, 2048, 44100.0, 1.0, 1535), (64, 23, 1024, 22050.0, 0.94, 1023),
+    (64, 200, 2048, 44100.0, 1.0, 1535)])
+def test_mel_lane_plan_walks_every_filter_once(pkg, lanes, nb, W2, sr, alpha, max_read):
+    """Lane plans of the fused kernels' mel walk (16 lanes per frame: k_front512; 64: k_front_reg): every filter sits in
+    exactly one (round, lane) slot; the lane's zero-padded weight row holds the filter's table weights at its bins, in
+    ascending order (one chain of multiply-adds = the reference's summation order, mfcccpu.cpp:192-220), and exact zeros
+    everywhere else; starts are even, rounds are whole 8-bin trips, reads stay inside the magnitude buffer; row strides
+    are odd in 16-byte words (the 16 lanes of a 16-byte LDS access then fall on disjoint bank quads)."""
+    wt, beg = pkg.host_mel_table(nb, W2, sr, 64.0, sr / 2, alpha)
+    pl = pkg.host_mel_lane_plan(lanes, wt, beg, max_read)
+    R, L, rs = pl["rounds"], pl["L"], pl["row_stride"]
+    assert R == (nb + lanes - 1) // lanes and rs % 4 == 0 and (rs // 4) % 2 == 1 and rs >= int(L.sum())
+    seen = set()
+    base = 0
+    for r in range(R):
+        assert L[r] % 8 == 0 and L[r] >= 8
+        for j in range(lanes):
+            m, st = int(pl["fid"][r, j]), int(pl["start"][r, j])
+            row = pl["w"][j, base:base + L[r]]
+            if m < 0:
+                assert not row.any()
+                continue
+            assert m not in seen and 0 <= m < nb
+            seen.add(m)
+            assert st % 2 == 0 and st >= 0 and st + L[r] - 1 <= max_read
+            want = np.zeros(L[r], np.float32)
+            b0, b1 = int(beg[m]), int(beg[m + 2])
+            assert st <= b0 and b1 - st <= L[r]
+            want[b0 - st:b1 - st] = wt[m & 1, b0:b1]
+            assert np.array_equal(row, want)
+        base += int(L[r])
+    assert seen == set(range(nb))
+    assert not pl["w"][:, base:].any()
+
+
+@pytest.mark.parametrize("nb,nc,c0", [(40, 13, False), (26, 13, False), (15, 12, True), (80, 13, False), (128, 40, False)])
+def test_dct_mfma_operands_are_the_matrix(pkg, nb, nc, c0):
+    """Operand table of the DCT on the matrix pipe: lane (k = lane >> 4, n = lane & 15) of K step j of tile t holds
+    dct[4 j + k][16 t + n] (the B fragment of v_mfma_f32_16x16x4_f32), zeros beyond the matrix; multiplying it out in
+    the instruction's order reproduces the DCT of a random vector."""
+    m = pkg.host_dct_matrix(nb, nc, c0, 22.0)
+    dl = m.shape[1]
+    ob = pkg.host_dct_mfma_operands(m)
+    tiles, ks = ob.shape[0], ob.shape[1]
+    assert tiles == (dl + 15) // 16 and ks == (nb + 3) // 4
+    full = np.zeros((4 * ks, 16 * tiles), np.float32)
+    full[:nb, :dl] = m
+    for t in range(tiles):
+        for j in range(ks):
+            for lane in range(64):
+                assert ob[t, j, lane] == full[4 * j + (lane >> 4), 16 * t + (lane & 15)]
+    x = np.random.default_rng(3).standard_normal(nb).astype(np.float32)
+    xa = np.zeros(4 * ks, np.float32)
+    xa[:nb] = x
+    out = np.zeros(16 * tiles, np.float64)
+    for t in range(tiles):
+        for j in range(ks):
+            for k in range(4):
+                out[16 * t:16 * t + 16] += xa[4 * j + k] * ob[t, j, 16 * k:16 * k + 16].astype(np.float64)
+    np.testing.assert_allclose(out[:dl], x.astype(np.float64) @ m.astype(np.float64), rtol=0, atol=1e-5)
+
+
 def test_frame_count_integer_vs_float32(pkg, orc):
     L = orc.lib()
     rng = np.random.default_rng(5)
