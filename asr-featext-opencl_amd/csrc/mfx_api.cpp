@@ -119,6 +119,9 @@ struct mfx_handle {
     std::vector<int64_t> utt_off, utt_len, utt_row;
     std::vector<Chunk> h_chunks;
     std::vector<int32_t> chunk_utt;      // utterance of every entry of h_chunks
+    std::vector<int32_t> utt_chunk0;     // [n_utt + 1] first chunk of every utterance (chunks are in utterance order)
+    hipStream_t stream_up = nullptr, stream_dn = nullptr; // sliced mfx_batch_run_host: upload / download beside the kernels
+    hipEvent_t ev_up[16] = {}, ev_run[16] = {};
     DevBuf<Chunk> d_chunks;
     DevBuf<Segment> d_segs;
     DevBuf<float> d_stats_batch, d_spec_slab, d_host_out;
@@ -438,6 +441,12 @@ extern "C" void mfx_destroy(mfx_handle *h)
     }
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_out_stage) (void)hipHostFree(h->h_out_stage);
+    if (h->stream_up) (void)hipStreamDestroy(h->stream_up);
+    if (h->stream_dn) (void)hipStreamDestroy(h->stream_dn);
+    for (int i = 0; i < 16; ++i) {
+        if (h->ev_up[i]) (void)hipEventDestroy(h->ev_up[i]);
+        if (h->ev_run[i]) (void)hipEventDestroy(h->ev_run[i]);
+    }
     for (auto &e : h->ev_copy)
         if (e) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -798,6 +807,12 @@ int download_rows(mfx_handle *h, float *dst, const float *d_src, size_t count)
     }
     if (h->h_out_stage_n < count) {
         if (h->h_out_stage) (void)hipHostFree(h->h_out_stage);
+    if (h->stream_up) (void)hipStreamDestroy(h->stream_up);
+    if (h->stream_dn) (void)hipStreamDestroy(h->stream_dn);
+    for (int i = 0; i < 16; ++i) {
+        if (h->ev_up[i]) (void)hipEventDestroy(h->ev_up[i]);
+        if (h->ev_run[i]) (void)hipEventDestroy(h->ev_run[i]);
+    }
         h->h_out_stage = nullptr;
         h->h_out_stage_n = 0;
         const size_t want = std::max(count, (size_t)h->cap_rows * h->width);
@@ -1413,6 +1428,10 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
             h->chunk_utt.insert(h->chunk_utt.end(), cut_utt.begin(), cut_utt.end());
         }
     }
+    h->utt_chunk0.assign((size_t)n_utt + 1, (int32_t)h->h_chunks.size());
+    for (size_t c = h->h_chunks.size(); c-- > 0;) h->utt_chunk0[h->chunk_utt[c]] = (int32_t)c;
+    for (int u = n_utt - 1; u >= 0; --u) // utterances without frames: empty chunk range
+        if (h->utt_chunk0[u] > h->utt_chunk0[u + 1]) h->utt_chunk0[u] = h->utt_chunk0[u + 1];
     h->total_rows = row;
     h->tiles_max = tiles_max;
     h->batch_aligned = aligned;
@@ -1435,26 +1454,40 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
     return MFX_OK;
 }
 
+namespace {
+// utterances [u0, u1) of the planned batch (all of them: the fused-delta and overlap modes apply)
+int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_total, float *d_out, int u0, int u1);
+} // namespace
+
 extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_total, float *d_out)
 {
     if (!h) return MFX_ERR_ARG;
+    return batch_run_range(h, d_pcm, pcm_samples_total, d_out, 0, h->n_utt);
+}
+
+namespace {
+int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_total, float *d_out, int u0, int u1)
+{
     if (!d_pcm || !d_out || pcm_samples_total <= 0) return fail(h, MFX_ERR_ARG, "invalid argument");
+    const bool whole = u0 == 0 && u1 == h->n_utt;
+    const int32_t rc0 = h->utt_chunk0[u0], rc1 = h->utt_chunk0[u1]; // chunk range of the utterance range
     if (!h->have_window) return fail(h, MFX_ERR_STATE, "set_window has not been called");
     if (h->total_rows == 0) return MFX_OK;
     if (((uintptr_t)d_pcm & 3) != 0) return fail(h, MFX_ERR_ARG, "d_pcm must be 4-byte aligned");
-    for (int u = 0; u < h->n_utt; ++u)
+    for (int u = u0; u < u1; ++u)
         if (h->utt_off[u] + h->utt_len[u] > pcm_samples_total)
             return fail(h, MFX_ERR_ARG, "utterance extends past the end of the PCM array");
     HIP_TRY(h, hipSetDevice(h->device));
     int rc = refresh_mel(h);
     if (rc != MFX_OK) return rc;
+    if (rc1 <= rc0) return MFX_OK;
 
     FrontParams p;
     fill_front(h, p);
     p.pcm = d_pcm;
     p.pcm_total = pcm_samples_total * h->channels;
-    p.chunks = h->d_chunks.p;
-    p.n_chunks = (int32_t)h->h_chunks.size();
+    p.chunks = h->d_chunks.p + rc0;
+    p.n_chunks = rc1 - rc0;
     p.row_limit = h->total_rows;
     p.feat = d_out;
     p.feat_pitch = h->width;
@@ -1473,19 +1506,19 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
     // Overlap (opt-in, mfx_batch_overlap): the delta/normalisation tail runs on a second stream behind an
     // event, so the memory-bound tail of batch i shares the GPU with the compute-bound front end of
     // batch i+1; the statics scratch is double buffered and the front end of batch i+2 waits for tail i.
-    const int sb = h->overlap ? (int)(h->batch_seq & 1) : 0;
+    const int sb = (h->overlap && whole) ? (int)(h->batch_seq & 1) : 0;
     const bool via_scratch = ((fused512 && p.dct_mode == 1) || fusedgen) && h->l1 > 0 && h->cols <= 16 && !norm_before &&
                              h->d_static16[sb].n >= (size_t)h->total_rows * 16;
     // Fused delta stage: the 512-point kernel's last wave per block turns the statics into whole output
     // rows while the other 15 produce them; no separate delta launch.
-    bool fuse = h->fuse_plan && fused512 && via_scratch && ((uintptr_t)d_out & 15) == 0;
+    bool fuse = whole && h->fuse_plan && fused512 && via_scratch && ((uintptr_t)d_out & 15) == 0;
     if (fuse) {
         p.dl1 = h->l1;
         p.dl2 = h->l2;
         p.done_words = h->f_done_words;
         fuse = p.dct_mode == 1 && front512_delta_lds_bytes(p) <= 160 * 1024;
     }
-    const bool split_tail = h->overlap && via_scratch && !fuse;
+    const bool split_tail = whole && h->overlap && via_scratch && !fuse;
     hipStream_t tail_stream = split_tail ? h->stream2 : h->stream;
     if (via_scratch) {
         p.feat = h->d_static16[sb].p;
@@ -1519,8 +1552,8 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
         const int64_t slab_rows = std::min<int64_t>(h->total_rows, slab_rows_max);
         if (h->d_spec_slab.n < (size_t)slab_rows * h->spec_pitch)
             HIP_TRY(h, h->d_spec_slab.alloc((size_t)slab_rows * h->spec_pitch));
-        size_t c0 = 0;
-        const size_t nchunks = h->h_chunks.size();
+        size_t c0 = (size_t)rc0;
+        const size_t nchunks = (size_t)rc1;
         while (c0 < nchunks) {
             const int64_t row0 = h->h_chunks[c0].out_row;
             size_t c1 = c0;
@@ -1577,7 +1610,8 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
     } swap_guard(h, tail_stream);
     const bool norm = h->cfg.norm != MFX_NORM_NONE;
     if (norm && !h->cfg.norm_after_dyn) {
-        rc = run_norm(h, d_out, h->width, 0, h->d_segs.p, h->n_utt, nullptr, 0, h->d_stats_batch.p, false, h->tiles_max * 64);
+        rc = run_norm(h, d_out, h->width, 0, h->d_segs.p + u0, u1 - u0, nullptr, 0, h->d_stats_batch.p + (size_t)u0 * 2 * h->cols,
+                      false, h->tiles_max * 64);
         if (rc != MFX_OK) return rc;
     }
     if (h->l1 > 0 && !fuse) {
@@ -1587,8 +1621,8 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
         dp.src_pitch = via_scratch ? 16 : h->width;
         dp.out = d_out;
         dp.out_pitch = h->width;
-        dp.segs = h->d_segs.p;
-        dp.n_segs = h->n_utt;
+        dp.segs = h->d_segs.p + u0;
+        dp.n_segs = u1 - u0;
         dp.cols = h->cols;
         dp.l1 = h->l1;
         dp.l2 = h->l2;
@@ -1598,8 +1632,8 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
     if (norm && h->cfg.norm_after_dyn) {
         const int groups = h->width / h->cols;
         for (int g = 0; g < groups; ++g) {
-            rc = run_norm(h, d_out, h->width, g * h->cols, h->d_segs.p, h->n_utt, nullptr, 0,
-                          h->d_stats_batch.p + (size_t)g * h->n_utt * 2 * h->cols, false, h->tiles_max * 64);
+            rc = run_norm(h, d_out, h->width, g * h->cols, h->d_segs.p + u0, u1 - u0, nullptr, 0,
+                          h->d_stats_batch.p + ((size_t)g * h->n_utt + u0) * 2 * h->cols, false, h->tiles_max * 64);
             if (rc != MFX_OK) return rc;
         }
     }
@@ -1607,9 +1641,10 @@ extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t
         HIP_TRY(h, hipEventRecord(h->ev_tail[sb], tail_stream));
         h->tail_pending[sb] = true;
     }
-    ++h->batch_seq;
+    if (whole) ++h->batch_seq;
     return MFX_OK;
 }
+} // namespace
 
 extern "C" int mfx_batch_overlap(mfx_handle *h, int enable)
 {
@@ -1642,6 +1677,51 @@ extern "C" int mfx_batch_run_host(mfx_handle *h, const int16_t *pcm, int64_t pcm
     const size_t n_out = (size_t)std::max<int64_t>(h->total_rows, 1) * h->width;
     if (h->d_host_pcm.n < n_in + 8) HIP_TRY(h, h->d_host_pcm.alloc(n_in + 8));
     if (h->d_host_out.n < n_out) HIP_TRY(h, h->d_host_out.alloc(n_out));
+
+    // Pinned caller buffers and a batch worth slicing: the utterances go through in up to 8 slices, the upload of slice
+    // k + 1 and the download of slice k - 1 running beside the kernels of slice k on their own streams (PCIe is full
+    // duplex: the 320 MB in and the 156 MB out of a C2 batch overlap instead of queueing up).  Utterance offsets must
+    // ascend for a slice to be one contiguous piece of the PCM array; anything else takes the plain path below.
+    bool ascending = true;
+    for (int u = 1; u < h->n_utt && ascending; ++u) ascending = h->utt_off[u] >= h->utt_off[u - 1] + h->utt_len[u - 1];
+    const int K = (int)std::min<int64_t>(8, h->n_utt / 4);
+    if (K >= 2 && ascending && !h->overlap && !h->fuse_plan && n_in * sizeof(int16_t) >= ((size_t)32 << 20) &&
+        is_pinned_host(pcm) && is_pinned_host(out)) {
+        if (!h->stream_up) {
+            HIP_TRY(h, hipStreamCreateWithFlags(&h->stream_up, hipStreamNonBlocking));
+            HIP_TRY(h, hipStreamCreateWithFlags(&h->stream_dn, hipStreamNonBlocking));
+            for (int i = 0; i < 16; ++i) {
+                HIP_TRY(h, hipEventCreateWithFlags(&h->ev_up[i], hipEventDisableTiming));
+                HIP_TRY(h, hipEventCreateWithFlags(&h->ev_run[i], hipEventDisableTiming));
+            }
+        }
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        const int ch = h->channels;
+        for (int k = 0; k < K; ++k) {
+            const int u0 = (int)((int64_t)h->n_utt * k / K), u1 = (int)((int64_t)h->n_utt * (k + 1) / K);
+            // samples [s0, s1) of the array hold the slice (s0 rounded down to an even sample: 4-byte aligned pieces)
+            const int64_t s0 = (k == 0 ? 0 : h->utt_off[u0]) & ~(int64_t)1;
+            const int64_t s1 = k + 1 == K ? pcm_samples_total : h->utt_off[u1];
+            HIP_TRY(h, hipMemcpyAsync(h->d_host_pcm.p + s0 * ch, pcm + s0 * ch, (size_t)(s1 - s0) * ch * sizeof(int16_t),
+                                      hipMemcpyHostToDevice, h->stream_up));
+            HIP_TRY(h, hipEventRecord(h->ev_up[k], h->stream_up));
+            HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_up[k], 0));
+            int rc = batch_run_range(h, h->d_host_pcm.p, pcm_samples_total, h->d_host_out.p, u0, u1);
+            if (rc != MFX_OK) {
+                (void)hipDeviceSynchronize();
+                return rc;
+            }
+            HIP_TRY(h, hipEventRecord(h->ev_run[k], h->stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->stream_dn, h->ev_run[k], 0));
+            const int64_t r0 = h->utt_row[u0], r1 = u1 < h->n_utt ? h->utt_row[u1] : h->total_rows;
+            if (r1 > r0)
+                HIP_TRY(h, hipMemcpyAsync(out + r0 * h->width, h->d_host_out.p + r0 * h->width,
+                                          (size_t)(r1 - r0) * h->width * sizeof(float), hipMemcpyDeviceToHost, h->stream_dn));
+        }
+        HIP_TRY(h, hipStreamSynchronize(h->stream_dn));
+        return mfx_synchronize(h);
+    }
+
     HIP_TRY(h, hipMemcpyAsync(h->d_host_pcm.p, pcm, n_in * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
     int rc = mfx_batch_run_device(h, h->d_host_pcm.p, pcm_samples_total, h->d_host_out.p);
     if (rc != MFX_OK) {

@@ -912,6 +912,36 @@ def test_random_ragged_batches(pkg, orc, case):
         assert_close(got[rows[i]:rows[i] + T], want, "utterance %d (%d frames)" % (i, T), groups=g)
 
 
+@pytest.mark.parametrize("norm", [0, 2])
+def test_batch_run_host_sliced_path_is_bit_identical(pkg, orc, norm):
+    """mfx_batch_run_host with PINNED caller buffers runs the batch in slices (upload of slice k + 1 and download of
+    slice k - 1 beside the kernels of slice k); with pageable buffers it runs it whole.  Same bits,
+    ragged utterances with gaps between them, odd sample counts included."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(9)
+    n_utt = 96
+    lens = [int(v) for v in rng.integers(150000, 200000, size=n_utt)]
+    offs, pos = [], 0
+    for n in lens:
+        offs.append(pos)
+        pos += n + int(rng.integers(0, 5))
+    pcm = (3000.0 * rng.standard_normal(pos)).astype(np.int16)
+    m, cfg, w = make_pair(pkg, orc, 210000, norm=norm)
+    rows, total = m.batch_plan(offs, lens)
+    plain = m.batch_run_host(pcm)                                 # pageable: one piece
+    t_in = torch.from_numpy(pcm).pin_memory()
+    t_out = torch.zeros((total, m.get_output_data_width()), dtype=torch.float32).pin_memory()
+    rc = m._L.mfx_batch_run_host(m._h, C.cast(t_in.data_ptr(), C.POINTER(C.c_int16)), pos,
+                                 C.cast(t_out.data_ptr(), C.POINTER(C.c_float)))
+    assert rc == 0
+    assert pos * 2 >= 32 << 20                                    # large enough for the sliced path
+    assert np.array_equal(t_out.numpy(), plain)
+    u = 57
+    assert_close(plain[rows[u]:rows[u] + 100], orc.run_utterance(cfg, pcm[offs[u]:offs[u] + lens[u]], w,
+                                                                 bug_compat=False)[:100], "utterance 57", groups=3) if norm == 0 else None
+
+
 def test_last_frame_ends_on_an_odd_last_sample(pkg, orc):
     """An utterance with an ODD number of samples whose last frame ends exactly on the last sample, at the very end of
     the PCM array: the last sample lies in a 32-bit word that is half past the end.  (Found by the widened random

@@ -12,7 +12,7 @@ done
 for f in bench_C2_default bench_C2_steps20_warmup5 bench_C3 bench_C5 bench_C4 bench_C2_gpus2_one_device_gloo; do
   [ -f "$T/$f.json" ] && cp "$T/$f.json" "$D/${P}_$f.json"
 done
-for f in stream_bench afet_bench; do [ -f "$T/$f.txt" ] && cp "$T/$f.txt" "$D/${P}_$f.txt"; done
+for f in stream_bench afet_bench host_batch_bench; do [ -f "$T/$f.txt" ] && cp "$T/$f.txt" "$D/${P}_$f.txt"; done
 # HBM traffic per workload for bench.py's roofline.traffic (labelled there as read from this file)
 python3 - "$R/profiles/traffic_latest.json" "$T" <<'PY'
 import json, os, sys

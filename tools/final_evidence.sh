@@ -4,7 +4,7 @@
 #   the driver's short protocol (--steps 20 --warmup 5); C3 / C5: line with CPU baseline, kernel stats, PMC passes +
 #   traffic; C4 line; the 2-rank self-launch rehearsed on one GPU.      tools/final_evidence.sh <tag> [parts]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-final}; PARTS=${2:-smoke,c2,c3,c5,c4,ranks,stream,afet}
+TAG=${1:-final}; PARTS=${2:-smoke,c2,c3,c5,c4,ranks,stream,afet,hostbatch}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 has() { case ",$PARTS," in *",$1,"*) return 0;; esac; return 1; }
@@ -49,3 +49,4 @@ if has c4; then timeout -k 10 400 python3 bench.py --workload C4 --steps 30 --wa
 if has ranks; then MFX_BENCH_DEVICE=0 MFX_BENCH_BACKEND=gloo timeout -k 10 400 python3 bench.py --gpus 2 --steps 100 --warmup 20 --no-cpu-baseline > "$O/bench_C2_gpus2_one_device_gloo.json" 2> "$O/bench_gpus2.err" || exit 1; python3 -c "import json,sys; d=json.load(open(sys.argv[1])); print('gpus2 (one device)', d['n_gpus'], d['value'], d['ms_per_step'])" "$O/bench_C2_gpus2_one_device_gloo.json"; fi
 if has stream; then timeout -k 10 300 python3 tools/stream_bench.py > "$O/stream_bench.txt" 2>&1 || exit 1; grep "C ABI" "$O/stream_bench.txt" | head -2; fi
 if has afet; then AFET_TIMING=--timing tools/afet_bench.sh 2048 > "$O/afet_bench.txt" 2>&1 || exit 1; grep "files/s" "$O/afet_bench.txt"; fi
+if has hostbatch; then timeout -k 10 300 python3 tools/host_batch_bench.py > "$O/host_batch_bench.txt" 2>&1 || exit 1; grep "host buffers" "$O/host_batch_bench.txt"; fi
