@@ -35,6 +35,7 @@ struct Options {
     int sample_limit = 10000000, device = 0;
     bool bug_compat = true;
     bool htk = false; // binary output in HTK parameter-file format instead of the reference's text rows
+    int format_threads = 4; // threads that format the text rows of a block (per worker)
     std::vector<int> devices; // --devs a,b,...: one worker (own MfccHip, own thread) per entry
 };
 
@@ -163,13 +164,10 @@ inline char *put_f(char *p, char *end, double v)
     return std::to_chars(p, end, v, std::chars_format::fixed, 6).ptr;
 }
 
-void write_rows(FILE *out, const float *rows, int n, int width, int first_frame, long double t0, long double dt,
-                std::vector<char> &buf)
+// rows [r0, r1) formatted into p; returns the end
+char *format_rows(char *p, char *end, const float *rows, int r0, int r1, int width, int first_frame, long double t0, long double dt)
 {
-    // a value needs at most 1 + 39 + 1 + 6 characters plus " |"; rows are formatted into one buffer and written once
-    buf.resize((size_t)n * ((size_t)width + 1) * 52 + 16);
-    char *p = buf.data(), *end = buf.data() + buf.size();
-    for (int f = 0; f < n; ++f) {
+    for (int f = r0; f < r1; ++f) {
         *p++ = '|';
         *p++ = ' ';
         p = put_f(p, end, (double)(t0 + (first_frame + f) * dt));
@@ -183,7 +181,31 @@ void write_rows(FILE *out, const float *rows, int n, int width, int first_frame,
         }
         *p++ = '\n';
     }
-    std::fwrite(buf.data(), 1, (size_t)(p - buf.data()), out);
+    return p;
+}
+
+void write_rows(FILE *out, const float *rows, int n, int width, int first_frame, long double t0, long double dt,
+                std::vector<char> &buf, int threads)
+{
+    // a value needs at most 1 + 39 + 1 + 6 characters plus " |"; the rows are formatted into one buffer (large blocks: by a
+    // few threads, each into its own share of the buffer) and written in order
+    const size_t per_row = ((size_t)width + 1) * 52 + 4;
+    buf.resize((size_t)n * per_row + 16);
+    const int T = (n >= 256 && threads > 1) ? std::min(threads, 4) : 1;
+    if (T == 1) {
+        char *p = format_rows(buf.data(), buf.data() + buf.size(), rows, 0, n, width, first_frame, t0, dt);
+        std::fwrite(buf.data(), 1, (size_t)(p - buf.data()), out);
+        return;
+    }
+    std::vector<std::thread> th;
+    std::vector<size_t> used((size_t)T, 0);
+    for (int t = 0; t < T; ++t) {
+        const int r0 = (int)((int64_t)n * t / T), r1 = (int)((int64_t)n * (t + 1) / T);
+        char *base = buf.data() + (size_t)r0 * per_row;
+        th.emplace_back([=, &used] { used[t] = (size_t)(format_rows(base, base + (size_t)(r1 - r0) * per_row, rows, r0, r1, width, first_frame, t0, dt) - base); });
+    }
+    for (auto &x : th) x.join();
+    for (int t = 0; t < T; ++t) std::fwrite(buf.data() + (size_t)((int64_t)n * t / T) * per_row, 1, used[t], out);
 }
 
 // --timing: wall time per phase, summed over the files of all workers (dev aid; printed at exit)
@@ -267,7 +289,7 @@ void process_file(MfccHip &param, const Options &o, const Wav &w, const std::str
             if (o.htk)
                 write_rows_htk(outs[i].second, rows.data(), n, width, sc.text);
             else
-                write_rows(outs[i].second, rows.data(), n, width, total, t0, dt, sc.text);
+                write_rows(outs[i].second, rows.data(), n, width, total, t0, dt, sc.text, o.format_threads);
             t0e = g_time.on ? now_ns() : 0;
             t_wr += t0e - t1e;
         }
@@ -399,6 +421,7 @@ int main(int argc, char **argv)
         else if (a == "--bug-compat") o.bug_compat = std::atoi(val()) != 0;
         else if (a == "--htk") o.htk = true;
         else if (a == "--timing") g_time.on = true;
+        else if (a == "--format-threads") o.format_threads = std::max(1, std::atoi(val()));
         else if (a == "--help") {
             std::printf("afet_hip [--window-size ms] [--shift ms] [--banks n] [--ceps n] [--c0 0|1] [--norm 0..3]\n"
                         "         [--dyn 0..2] [--l1 n] [--l2 n] [--low-freq hz] [--high-freq hz] [--lift-coef x]\n"
