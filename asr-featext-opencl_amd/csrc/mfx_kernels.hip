@@ -77,16 +77,20 @@ __device__ __forceinline__ void fft16(float2 (&x)[16])
     for (int n2 = 0; n2 < 4; ++n2)
         dft4(x[n2], x[4 + n2], x[8 + n2], x[12 + n2], y[0 + n2], y[4 + n2], y[8 + n2], y[12 + n2]);
     // y[4*k1 + n2] *= W16^(n2*k1)
+    // (written with negative constants instead of subtracted products: "a * K + b * (-K2)" compiles to v_mul + v_fmamk with
+    // literal constants, which issue at full rate; "a * K - b * K2" takes a VOP3 fma with a negated operand and the
+    // constant in a scalar register, which issues at half rate -- tools/ubench/valu_forms.hip)
+    constexpr float nC1 = -C1, nS1 = -S1, nR = -R;
     float2 t;
-    t = y[4 + 1];  y[4 + 1]  = make_float2(t.x * C1 + t.y * S1, t.y * C1 - t.x * S1);     // W^1
+    t = y[4 + 1];  y[4 + 1]  = make_float2(t.x * C1 + t.y * S1, t.y * C1 + t.x * nS1);    // W^1
     t = y[4 + 2];  y[4 + 2]  = make_float2(R * (t.x + t.y), R * (t.y - t.x));             // W^2
-    t = y[4 + 3];  y[4 + 3]  = make_float2(t.x * S1 + t.y * C1, t.y * S1 - t.x * C1);     // W^3
+    t = y[4 + 3];  y[4 + 3]  = make_float2(t.x * S1 + t.y * C1, t.y * S1 + t.x * nC1);    // W^3
     t = y[8 + 1];  y[8 + 1]  = make_float2(R * (t.x + t.y), R * (t.y - t.x));             // W^2
     t = y[8 + 2];  y[8 + 2]  = make_float2(t.y, -t.x);                                    // W^4
-    t = y[8 + 3];  y[8 + 3]  = make_float2(R * (t.y - t.x), -R * (t.x + t.y));            // W^6
-    t = y[12 + 1]; y[12 + 1] = make_float2(t.x * S1 + t.y * C1, t.y * S1 - t.x * C1);     // W^3
-    t = y[12 + 2]; y[12 + 2] = make_float2(R * (t.y - t.x), -R * (t.x + t.y));            // W^6
-    t = y[12 + 3]; y[12 + 3] = make_float2(-(t.x * C1 + t.y * S1), t.x * S1 - t.y * C1);  // W^9
+    t = y[8 + 3];  y[8 + 3]  = make_float2(R * (t.y - t.x), nR * (t.x + t.y));            // W^6
+    t = y[12 + 1]; y[12 + 1] = make_float2(t.x * S1 + t.y * C1, t.y * S1 + t.x * nC1);    // W^3
+    t = y[12 + 2]; y[12 + 2] = make_float2(R * (t.y - t.x), nR * (t.x + t.y));            // W^6
+    t = y[12 + 3]; y[12 + 3] = make_float2(t.x * nC1 + t.y * nS1, t.x * S1 + t.y * nC1);  // W^9
 #pragma unroll
     for (int k1 = 0; k1 < 4; ++k1)
         dft4(y[4 * k1], y[4 * k1 + 1], y[4 * k1 + 2], y[4 * k1 + 3], x[k1], x[k1 + 4], x[k1 + 8], x[k1 + 12]);
@@ -912,7 +916,9 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
                 // them so that the 16 lanes of a slot (and the neighbouring slot, skewed by 32 dwords)
                 // fall on distinct bank pairs.
                 const float *wrow = s_melw + l * RS;
-                float *dst = p.feat + (out_row + (live ? f : 0)) * (int64_t)p.feat_pitch;
+                // (uniform base of the iteration's first row + this lane's row inside the iteration: the compiler keeps the
+                // 64-bit part in scalar registers; rows past the chunk are never stored, so their address needs no clamp)
+                float *dst = p.feat + (out_row + f0) * (int64_t)p.feat_pitch + slot * p.feat_pitch;
                 if (p.dct_mode == 1) {
                     // log mel energies to the frame's LDS row (8 dwords of skew per slot: the operand reads below
                     // then fall on distinct banks), then the DCT-II + lifter (mfcccpu.cpp:222-232) as ONE chain of
