@@ -1275,8 +1275,10 @@ __device__ __forceinline__ int pad_idx(int i)
 }
 
 // s_tw: this pass's twiddles W_LEN^(pp k) laid out [k - 1][pp], pp < LEN / R (unused by the last pass)
-template <int M, int R, int LEN, bool FROM_REGS, int LP>
-__device__ __forceinline__ void stockham_pass(float2 *buf, const float2 *s_tw, int lane, float2 (&v)[M / 64])
+// TWREG: the pass's twiddles are already in registers (twr[k - 1], one butterfly per lane: they depend on the lane only)
+template <int M, int R, int LEN, bool FROM_REGS, int LP, bool TWREG = false>
+__device__ __forceinline__ void stockham_pass(float2 *buf, const float2 *s_tw, int lane, float2 (&v)[M / 64],
+                                              const float2 *twr = nullptr)
 {
     constexpr int ST = M / LEN, N1 = LEN / R, NB = M / R / 64;
     static_assert(NB >= 1, "a pass needs at least one butterfly per lane");
@@ -1298,7 +1300,7 @@ __device__ __forceinline__ void stockham_pass(float2 *buf, const float2 *s_tw, i
 #pragma unroll
         for (int k = 1; k < R; ++k)
             buf[pad_idx<LP>(q + ST * (R * pp + k))] =
-                (LEN == R) ? w[k] : cmul(w[k], s_tw[(k - 1) * N1 + pp]); // W_LEN^(pp k)
+                (LEN == R) ? w[k] : cmul(w[k], TWREG ? twr[k - 1] : s_tw[(k - 1) * N1 + pp]); // W_LEN^(pp k)
     }
     wave_sync();
 }
@@ -1356,50 +1358,101 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
     }
     __syncthreads();
 
+    // 1024 points, one word per sample pair: 40 registers are free at 16 waves per CU -- the twiddles of passes 1 and 2
+    // (7 + 7 complex values that depend on the lane only) live in registers instead of being read from LDS every frame
+#ifdef MFX_NO_TWREG
+    constexpr bool TWREG = false;
+#else
+    constexpr bool TWREG = LOG2M == 9 && PAIR && FUSED;
+#endif
+    float2 tw1[R1 - 1], tw2[R2 - 1];
+    if (TWREG) {
+#pragma unroll
+        for (int k = 1; k < R1; ++k) tw1[k - 1] = s_tw[(k - 1) * (M / R1) + lane];                      // W_M^(lane k)
+#pragma unroll
+        for (int k = 1; k < R2; ++k) tw2[k - 1] = s_tw[NT1 + (k - 1) * (M / (R1 * R2)) + lane / R1];  // W_(M/R1)^(pp k), pp = lane / R1
+    }
     const int ch_n = p.channels, W = p.window_size;
-    for (int c = blockIdx.x * n_waves + wave; c < p.n_chunks; c += gridDim.x * n_waves) {
+    // Raw samples of ONE frame as loaded (PAIR / mono: one 32-bit word per sample pair; stereo: two).  The next frame's
+    // words are requested as soon as this frame's have been converted, so their latency runs under the transform.
+    constexpr int NJ = HALF ? NV / 2 : NV;   // sample pairs per lane that can carry window taps
+    constexpr int NRAW = PAIR ? NJ : 2 * NJ;
+    uint32_t raw[NRAW];
+    struct __attribute__((aligned(4))) Pair32 {
+        uint32_t x, y;
+    };
+    typedef uint32_t __attribute__((aligned(2))) u32_a2;
+    auto issue = [&](int64_t s0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = lane + 64 * j;
+            if (PAIR) {
+                raw[j] = 0u;
+                if (2 * n < W) raw[j] = ((const uint32_t *)(p.pcm + s0))[n];
+            } else if (ch_n == 2) {
+                // interleaved stereo: sample s is one aligned 32-bit word (L | R << 16); mono = (L + R) >> 1.
+                // The pair (s, s + 1) comes as ONE 8-byte load at 4-byte alignment (consecutive lanes then
+                // cover 512 contiguous bytes); an odd window's last pair re-reads its own sample instead
+                // of the one past the frame.
+                raw[2 * j] = raw[2 * j + 1] = 0u;
+                if (2 * n < W) {
+                    const bool has1 = 2 * n + 1 < W;
+                    const uint32_t *w32 = (const uint32_t *)p.pcm + (s0 + 2 * n) - (has1 ? 0 : 1);
+                    const Pair32 dd = *(const Pair32 *)w32;
+                    raw[2 * j] = dd.x;
+                    raw[2 * j + 1] = dd.y;
+                }
+            } else {
+                // mono at an odd sample offset: the pair as ONE 4-byte load at 2-byte alignment
+                raw[2 * j] = raw[2 * j + 1] = 0u;
+                if (2 * n < W) {
+                    const bool has1 = 2 * n + 1 < W;
+                    raw[2 * j] = *(const u32_a2 *)(p.pcm + s0 + 2 * n - (has1 ? 0 : 1));
+                }
+            }
+        }
+    };
+    // (only the builds that load one word per sample pair: the stereo / odd-offset builds hold two words per pair and
+    // have no registers to spare -- with the prefetch the 2048-point stereo build spilled 71 registers, 1.18 ms against 1.02)
+    constexpr bool PREFETCH = PAIR && (FUSED || LOG2M == 9);
+    const int c_step = gridDim.x * n_waves;
+    bool fetched = false; // raw holds the frame about to be worked on
+    for (int c = blockIdx.x * n_waves + wave; c < p.n_chunks; c += c_step) {
         const Chunk ch = p.chunks[c];
         const int64_t rows_left = p.row_limit - ch.out_row;
         const int nf = (int)(rows_left < ch.n_frames ? (rows_left < 0 ? 0 : rows_left) : ch.n_frames);
+        // the chunk after this one (its first frame is requested during this chunk's last)
+        const bool more = c + c_step < p.n_chunks;
+        const Chunk chn = p.chunks[more ? c + c_step : c];
+        const int64_t rows_left_n = p.row_limit - chn.out_row;
+        const bool next_has = more && chn.n_frames > 0 && rows_left_n > 0;
         for (int f = 0; f < nf; ++f) {
             const int64_t s0 = ch.pcm_off + (int64_t)f * p.shift;
+            if (!fetched) issue(s0);
             // ---- framing + window, straight into the registers of pass 1: z[n], n = lane + 64 j
             float2 v[NV];
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int n = lane + 64 * j;
-                if (HALF && j >= NV / 2) { // 2 n >= M >= W: no taps here
+                if (j >= NJ) { // 2 n >= M >= W: no taps here
                     v[j] = make_float2(0.f, 0.f);
                     continue;
                 }
                 float x0 = 0.f, x1 = 0.f;
-                if (2 * n < W) {
-                    if (PAIR) {
-                        const uint32_t d = ((const uint32_t *)(p.pcm + s0))[n];
-                        x0 = (float)(int)(short)(d & 0xffffu);
-                        x1 = (float)((int)d >> 16);
-                    } else if (ch_n == 2) {
-                        // interleaved stereo: sample s is one aligned 32-bit word (L | R << 16); mono = (L + R) >> 1.
-                        // The pair (s, s + 1) comes as ONE 8-byte load at 4-byte alignment (consecutive lanes then
-                        // cover 512 contiguous bytes); an odd window's last pair re-reads its own sample instead
-                        // of the one past the frame.
-                        struct __attribute__((aligned(4))) Pair32 {
-                            uint32_t x, y;
-                        };
-                        const bool has1 = 2 * n + 1 < W;
-                        const uint32_t *w32 = (const uint32_t *)p.pcm + (s0 + 2 * n) - (has1 ? 0 : 1);
-                        const Pair32 dd = *(const Pair32 *)w32;
-                        const uint32_t d0 = has1 ? dd.x : dd.y, d1 = dd.y;
-                        x0 = (float)(((int)(short)(d0 & 0xffffu) + ((int)d0 >> 16)) >> 1);
-                        if (has1) x1 = (float)(((int)(short)(d1 & 0xffffu) + ((int)d1 >> 16)) >> 1);
-                    } else {
-                        // mono at an odd sample offset: the pair as ONE 4-byte load at 2-byte alignment
-                        typedef uint32_t __attribute__((aligned(2))) u32_a2;
-                        const bool has1 = 2 * n + 1 < W;
-                        const uint32_t d = *(const u32_a2 *)(p.pcm + s0 + 2 * n - (has1 ? 0 : 1));
-                        x0 = (float)(int)(short)(has1 ? (d & 0xffffu) : (d >> 16));
-                        if (has1) x1 = (float)((int)d >> 16);
-                    }
+                if (PAIR) {
+                    const uint32_t d = raw[j];
+                    x0 = (float)(int)(short)(d & 0xffffu);
+                    x1 = (float)((int)d >> 16);
+                } else if (ch_n == 2) {
+                    const bool has1 = 2 * n + 1 < W;
+                    const uint32_t d0 = has1 ? raw[2 * j] : raw[2 * j + 1], d1 = raw[2 * j + 1];
+                    x0 = (float)(((int)(short)(d0 & 0xffffu) + ((int)d0 >> 16)) >> 1);
+                    if (has1) x1 = (float)(((int)(short)(d1 & 0xffffu) + ((int)d1 >> 16)) >> 1);
+                } else {
+                    const bool has1 = 2 * n + 1 < W;
+                    const uint32_t d = raw[2 * j];
+                    x0 = (float)(int)(short)(has1 ? (d & 0xffffu) : (d >> 16));
+                    if (has1) x1 = (float)((int)d >> 16);
                 }
                 const float2 w = 64 * j < nwin ? s_win[n] : make_float2(0.f, 0.f); // (rows past the window: no table)
                 v[j] = make_float2(w.x * x0, w.y * x1);
@@ -1416,8 +1469,8 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
                     for (int j = 0; j < NV; ++j) v[j] = t[j];
                 }
             }
-            stockham_pass<M, R1, M, true, LP>(buf, s_tw, lane, v);
-            stockham_pass<M, R2, M / R1, false, LP>(buf, s_tw + NT1, lane, v);
+            stockham_pass<M, R1, M, true, LP, TWREG>(buf, s_tw, lane, v, tw1);
+            stockham_pass<M, R2, M / R1, false, LP, TWREG>(buf, s_tw + NT1, lane, v, tw2);
             stockham_pass<M, R3, R3, false, LP>(buf, s_tw, lane, v);
 
             // ---- real split over the bin pairs (k, M - k), k = lane + 64 j <= M/2, and the magnitudes
@@ -1434,6 +1487,15 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
                 const float ar = sr + tr, ai = si + ti, br = sr - tr, bi = si - ti;
                 mag_lo[j] = __builtin_amdgcn_sqrtf(ar * ar + ai * ai); // |X[k]| / W2
                 mag_hi[j] = __builtin_amdgcn_sqrtf(br * br + bi * bi); // |X[M - k]| / W2
+            }
+            // Request the next frame of this wave (the chunk's next one, or the first frame of the wave's next chunk) here,
+            // where few registers are live: the words arrive under the mel / DCT stage (or the spectrum stores).
+            if (PREFETCH) {
+                fetched = f + 1 < nf || next_has;
+                if (f + 1 < nf)
+                    issue(s0 + p.shift);
+                else if (next_has)
+                    issue(chn.pcm_off);
             }
             wave_sync();
 #if defined(MFX_ABLATE_REG) && MFX_ABLATE_REG >= 1
