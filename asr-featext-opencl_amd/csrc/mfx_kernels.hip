@@ -1296,11 +1296,17 @@ __device__ __forceinline__ void stockham_pass(float2 *buf, const float2 *s_tw, i
         const int idx = lane + 64 * b, pp = idx / ST, q = idx % ST;
         float2(&w)[R] = reinterpret_cast<float2(&)[R]>(v[b * R]);
         fft_r<R>(w);
-        buf[pad_idx<LP>(q + ST * (R * pp))] = w[0];
+        // The last pass leaves Z[lane + 64 j], j = b + NB k, in the lane's registers: the real split takes its own
+        // bins (j < NV / 2) from there, only the upper half -- the partners Z[M - k] -- goes through LDS.
+        if (LEN != R) buf[pad_idx<LP>(q + ST * (R * pp))] = w[0];
 #pragma unroll
-        for (int k = 1; k < R; ++k)
-            buf[pad_idx<LP>(q + ST * (R * pp + k))] =
-                (LEN == R) ? w[k] : cmul(w[k], TWREG ? twr[k - 1] : s_tw[(k - 1) * N1 + pp]); // W_LEN^(pp k)
+        for (int k = 1; k < R; ++k) {
+            if (LEN == R) {
+                if (k >= R / 2) buf[pad_idx<LP>(q + ST * (R * pp + k))] = w[k];
+            } else {
+                buf[pad_idx<LP>(q + ST * (R * pp + k))] = cmul(w[k], TWREG ? twr[k - 1] : s_tw[(k - 1) * N1 + pp]); // W_LEN^(pp k)
+            }
+        }
     }
     wave_sync();
 }
@@ -1363,7 +1369,7 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
 #ifdef MFX_NO_TWREG
     constexpr bool TWREG = false;
 #else
-    constexpr bool TWREG = LOG2M == 9 && PAIR && FUSED;
+    constexpr bool TWREG = LOG2M == 9 && PAIR && FUSED && HALF; // (a full-length window needs the registers for its samples)
 #endif
     float2 tw1[R1 - 1], tw2[R2 - 1];
     if (TWREG) {
@@ -1373,11 +1379,10 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
         for (int k = 1; k < R2; ++k) tw2[k - 1] = s_tw[NT1 + (k - 1) * (M / (R1 * R2)) + lane / R1];  // W_(M/R1)^(pp k), pp = lane / R1
     }
     const int ch_n = p.channels, W = p.window_size;
-    // Raw samples of ONE frame as loaded (PAIR / mono: one 32-bit word per sample pair; stereo: two).  The next frame's
-    // words are requested as soon as this frame's have been converted, so their latency runs under the transform.
+    // PREFETCH: the raw samples of the NEXT frame (one 32-bit word per sample pair) are requested while this frame's mel
+    // stage runs, so their latency never shows.
     constexpr int NJ = HALF ? NV / 2 : NV;   // sample pairs per lane that can carry window taps
-    constexpr int NRAW = PAIR ? NJ : 2 * NJ;
-    uint32_t raw[NRAW];
+    uint32_t raw[NJ];
     struct __attribute__((aligned(4))) Pair32 {
         uint32_t x, y;
     };
@@ -1386,30 +1391,8 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = lane + 64 * j;
-            if (PAIR) {
-                raw[j] = 0u;
-                if (2 * n < W) raw[j] = ((const uint32_t *)(p.pcm + s0))[n];
-            } else if (ch_n == 2) {
-                // interleaved stereo: sample s is one aligned 32-bit word (L | R << 16); mono = (L + R) >> 1.
-                // The pair (s, s + 1) comes as ONE 8-byte load at 4-byte alignment (consecutive lanes then
-                // cover 512 contiguous bytes); an odd window's last pair re-reads its own sample instead
-                // of the one past the frame.
-                raw[2 * j] = raw[2 * j + 1] = 0u;
-                if (2 * n < W) {
-                    const bool has1 = 2 * n + 1 < W;
-                    const uint32_t *w32 = (const uint32_t *)p.pcm + (s0 + 2 * n) - (has1 ? 0 : 1);
-                    const Pair32 dd = *(const Pair32 *)w32;
-                    raw[2 * j] = dd.x;
-                    raw[2 * j + 1] = dd.y;
-                }
-            } else {
-                // mono at an odd sample offset: the pair as ONE 4-byte load at 2-byte alignment
-                raw[2 * j] = raw[2 * j + 1] = 0u;
-                if (2 * n < W) {
-                    const bool has1 = 2 * n + 1 < W;
-                    raw[2 * j] = *(const u32_a2 *)(p.pcm + s0 + 2 * n - (has1 ? 0 : 1));
-                }
-            }
+            raw[j] = 0u;
+            if (2 * n < W) raw[j] = ((const uint32_t *)(p.pcm + s0))[n];
         }
     };
     // (only the builds that load one word per sample pair: the stereo / odd-offset builds hold two words per pair and
@@ -1428,7 +1411,7 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
         const bool next_has = more && chn.n_frames > 0 && rows_left_n > 0;
         for (int f = 0; f < nf; ++f) {
             const int64_t s0 = ch.pcm_off + (int64_t)f * p.shift;
-            if (!fetched) issue(s0);
+            if (PREFETCH && !fetched) issue(s0);
             // ---- framing + window, straight into the registers of pass 1: z[n], n = lane + 64 j
             float2 v[NV];
 #pragma unroll
@@ -1439,20 +1422,33 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
                     continue;
                 }
                 float x0 = 0.f, x1 = 0.f;
-                if (PAIR) {
+                if (PREFETCH) { // (PAIR builds only)
                     const uint32_t d = raw[j];
                     x0 = (float)(int)(short)(d & 0xffffu);
                     x1 = (float)((int)d >> 16);
-                } else if (ch_n == 2) {
-                    const bool has1 = 2 * n + 1 < W;
-                    const uint32_t d0 = has1 ? raw[2 * j] : raw[2 * j + 1], d1 = raw[2 * j + 1];
-                    x0 = (float)(((int)(short)(d0 & 0xffffu) + ((int)d0 >> 16)) >> 1);
-                    if (has1) x1 = (float)(((int)(short)(d1 & 0xffffu) + ((int)d1 >> 16)) >> 1);
-                } else {
-                    const bool has1 = 2 * n + 1 < W;
-                    const uint32_t d = raw[2 * j];
-                    x0 = (float)(int)(short)(has1 ? (d & 0xffffu) : (d >> 16));
-                    if (has1) x1 = (float)((int)d >> 16);
+                } else if (2 * n < W) { // loaded where it is consumed
+                    if (PAIR) {
+                        const uint32_t d = ((const uint32_t *)(p.pcm + s0))[n];
+                        x0 = (float)(int)(short)(d & 0xffffu);
+                        x1 = (float)((int)d >> 16);
+                    } else if (ch_n == 2) {
+                        // interleaved stereo: sample s is one aligned 32-bit word (L | R << 16); mono = (L + R) >> 1.
+                        // The pair (s, s + 1) comes as ONE 8-byte load at 4-byte alignment (consecutive lanes then
+                        // cover 512 contiguous bytes); an odd window's last pair re-reads its own sample instead
+                        // of the one past the frame.
+                        const bool has1 = 2 * n + 1 < W;
+                        const uint32_t *w32 = (const uint32_t *)p.pcm + (s0 + 2 * n) - (has1 ? 0 : 1);
+                        const Pair32 dd = *(const Pair32 *)w32;
+                        const uint32_t d0 = has1 ? dd.x : dd.y, d1 = dd.y;
+                        x0 = (float)(((int)(short)(d0 & 0xffffu) + ((int)d0 >> 16)) >> 1);
+                        if (has1) x1 = (float)(((int)(short)(d1 & 0xffffu) + ((int)d1 >> 16)) >> 1);
+                    } else {
+                        // mono at an odd sample offset: the pair as ONE 4-byte load at 2-byte alignment
+                        const bool has1 = 2 * n + 1 < W;
+                        const uint32_t d = *(const u32_a2 *)(p.pcm + s0 + 2 * n - (has1 ? 0 : 1));
+                        x0 = (float)(int)(short)(has1 ? (d & 0xffffu) : (d >> 16));
+                        if (has1) x1 = (float)((int)d >> 16);
+                    }
                 }
                 const float2 w = 64 * j < nwin ? s_win[n] : make_float2(0.f, 0.f); // (rows past the window: no table)
                 v[j] = make_float2(w.x * x0, w.y * x1);
@@ -1479,7 +1475,12 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
 #pragma unroll
             for (int j = 0; j <= NP; ++j) {
                 const int k = (j < NP) ? lane + 64 * j : M / 2;
-                const float2 zk = buf[pad_idx<LP>(k)], zm = buf[pad_idx<LP>((M - k) & (M - 1))];
+                // own bin from the last pass's registers (v[b R3 + kk] = Z[lane + 64 (b + NB3 kk)]); the partner from LDS.
+                // Z[0] pairs with itself (lower half, not in LDS), Z[M/2] too (upper half: read back by lane 0 ... all lanes)
+                constexpr int NB3 = M / R3 / 64;
+                float2 zm = buf[pad_idx<LP>(j < NP ? (((M - k) & (M - 1)) | (M / 2)) : M / 2)];
+                const float2 zk = j < NP ? v[(j % NB3) * R3 + j / NB3] : zm;
+                if (j == 0 && lane == 0) zm = zk;
                 const float sr = zk.x + zm.x, si = zk.y - zm.y;
                 const float dr = zk.x - zm.x, di = zk.y + zm.y;
                 const float2 w = s_cs[k];
