@@ -1209,7 +1209,7 @@ __host__ __device__ inline int lm_stride(int nb)
 }
 
 #ifndef MFX_REG10_THREADS
-#define MFX_REG10_THREADS 512   // threads per block of the fused 2048-point build (sets its register budget)
+#define MFX_REG10_THREADS 768   // most threads per block of the fused 2048-point build (sets its register budget: 168)
 #endif
 
 // window pairs k_front_reg keeps in LDS: the 64-pair rows that carry taps (a 25 ms window zero padded to the transform
@@ -1324,7 +1324,8 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
     constexpr int LP = (LOG2M == 9) ? 3 : 4, MP = M;             // swizzled buffer (pad_idx)
 #endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
+    const int tid = threadIdx.x, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    int lane = tid & 63;
     const int nb = p.num_banks, dl = p.dct_len;
     // shared tables, then one buffer of M complex points (+ mel scratch) per wave
     constexpr int NT1 = (R1 - 1) * (M / R1), NT2 = (R2 - 1) * (M / (R1 * R2));
@@ -1365,16 +1366,25 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
     __syncthreads();
 
     // 1024 points, one word per sample pair: 40 registers are free at 16 waves per CU -- the twiddles of passes 1 and 2
-    // (7 + 7 complex values that depend on the lane only) live in registers instead of being read from LDS every frame
+    // (7 + 7 complex values that depend on the lane only) live in registers instead of being read from LDS every frame.
+    // 2048 points, stereo / odd-offset build: 15 + 15 values, inside the 168-register budget of 12 waves per CU.
 #ifdef MFX_NO_TWREG
-    constexpr bool TWREG = false;
+    constexpr bool TWREG = false, TWREG_2 = false;
 #else
-    constexpr bool TWREG = LOG2M == 9 && PAIR && FUSED && HALF; // (a full-length window needs the registers for its samples)
+#ifndef MFX_TWREG10
+#define MFX_TWREG10 2
+#endif
+    constexpr bool TW10 = LOG2M == 10 && FUSED && !PAIR;
+    constexpr bool TWREG = (LOG2M == 9 && PAIR && FUSED && HALF) // (a full-length window needs the registers for its samples)
+                           || (TW10 && MFX_TWREG10 >= 1);
+    constexpr bool TWREG_2 = TWREG && (!TW10 || MFX_TWREG10 >= 2);
 #endif
     float2 tw1[R1 - 1], tw2[R2 - 1];
     if (TWREG) {
 #pragma unroll
         for (int k = 1; k < R1; ++k) tw1[k - 1] = s_tw[(k - 1) * (M / R1) + lane];                      // W_M^(lane k)
+    }
+    if (TWREG_2) {
 #pragma unroll
         for (int k = 1; k < R2; ++k) tw2[k - 1] = s_tw[NT1 + (k - 1) * (M / (R1 * R2)) + lane / R1];  // W_(M/R1)^(pp k), pp = lane / R1
     }
@@ -1410,6 +1420,13 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
         const int64_t rows_left_n = p.row_limit - chn.out_row;
         const bool next_has = more && chn.n_frames > 0 && rows_left_n > 0;
         for (int f = 0; f < nf; ++f) {
+#ifndef MFX_REG_NO_LAUNDER
+            // 2048 points: every frame re-derives its LDS addresses from the lane number (one or two vector instructions
+            // each) instead of holding a hundred loop-invariant addresses in registers -- 99 registers instead of 215, so
+            // 10 - 12 waves fit a CU instead of 8 (C5: 1.02 -> 0.92 ms; at equal occupancy the extra instructions cost
+            // 6 %; at 1024 points, where 16 waves fit anyway, they cost 17 % and the build keeps its addresses)
+            if (LOG2M == 10 && FUSED) asm volatile("" : "+v"(lane));
+#endif
             const int64_t s0 = ch.pcm_off + (int64_t)f * p.shift;
             if (PREFETCH && !fetched) issue(s0);
             // ---- framing + window, straight into the registers of pass 1: z[n], n = lane + 64 j
@@ -1466,7 +1483,7 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
                 }
             }
             stockham_pass<M, R1, M, true, LP, TWREG>(buf, s_tw, lane, v, tw1);
-            stockham_pass<M, R2, M / R1, false, LP, TWREG>(buf, s_tw + NT1, lane, v, tw2);
+            stockham_pass<M, R2, M / R1, false, LP, TWREG_2>(buf, s_tw + NT1, lane, v, tw2);
             stockham_pass<M, R3, R3, false, LP>(buf, s_tw, lane, v);
 
             // ---- real split over the bin pairs (k, M - k), k = lane + 64 j <= M/2, and the magnitudes
@@ -2032,8 +2049,9 @@ size_t front_reg_lds_floats(const FrontParams &p, bool fused, int n_waves)
 int front_reg_waves(const FrontParams &p, bool fused)
 {
     // (4096 points: 4 waves -- the kernel is built for 256 threads there, its 32 points per lane need the registers)
-    // (2048 points fused: 8 waves -- its tables leave no room for more, and the build allows 256 registers there)
-    const int top = p.fft_size >= 4096 ? 4 : (p.fft_size == 2048 && fused) ? MFX_REG10_THREADS / 64 : 16;
+    // (2048 points fused: one block of 10 waves -- tables + 12 buffers are all the LDS holds, and the throughput is flat
+    // from 10 waves up: C5 0.880 / 0.887 / 0.891 ms at 10 / 11 / 12 waves, 1.04 at 9, 1.10 at 8)
+    const int top = p.fft_size >= 4096 ? 4 : (p.fft_size == 2048 && fused) ? (MFX_REG10_THREADS / 64 < 10 ? MFX_REG10_THREADS / 64 : 10) : 16;
     // The block size that puts most waves on a CU (every block carries its own copy of the tables).  1024 points: at
     // 16 waves per CU two blocks of 8 beat one block of 16 (C3: 0.368 against 0.418 ms; 4 x 4: 0.431, 2 x 9 and 1 x 10
     // do not fit twice and lose) -- blocks that run out of step with each other spread their LDS phases.
@@ -2041,7 +2059,7 @@ int front_reg_waves(const FrontParams &p, bool fused)
     for (int nw = top; nw >= 4; --nw) {
         const size_t lds = front_reg_lds_floats(p, fused, nw) * sizeof(float);
         if (lds > 160 * 1024) continue;
-        const int cu_waves = p.fft_size == 2048 ? 8 : 16; // (2048 points: 190 registers -> 2 waves per SIMD)
+        const int cu_waves = p.fft_size == 2048 ? MFX_REG10_THREADS / 64 : 16; // (2048 points: one block per CU)
         int per_cu = p.fft_size <= 2048 ? (int)((160 * 1024) / lds) : 1;
         if (per_cu * nw > cu_waves) per_cu = cu_waves / nw;
         if (per_cu < 1) continue;
