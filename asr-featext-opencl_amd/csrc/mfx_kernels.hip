@@ -1577,27 +1577,42 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
                     if (p.dct_b) {
                         const float *arow = lm + (n >> 2) * nbp + gi;
                         const int ks = p.dct_ksteps;
-                        for (int t = 0; t < p.dct_tiles; ++t) {
-                            const float *bp = p.dct_b + (int64_t)t * ks * 64 + lane;
-                            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-                            // K steps in batches of 8: the batch's operand loads (8 from L1 / L2, 8 from LDS) are all in
-                            // flight before its first matrix instruction; steps past the matrix get zero operands
+                        // up to TG tiles of 16 columns share one walk over the K steps: the A operands (the frames' log
+                        // energies) are read once for all of them, and a batch of 8 steps waits once for its operands
+                        // (TG = 3 where the register budget allows: the 2048-point builds)
+                        constexpr int TG = LOG2M == 10 ? 3 : 1;
+                        for (int t0 = 0; t0 < p.dct_tiles; t0 += TG) {
+                            const int nt = p.dct_tiles - t0 < TG ? p.dct_tiles - t0 : TG;
+                            const float *bp = p.dct_b + (int64_t)t0 * ks * 64 + lane;
+                            f32x4 d0[TG], d1[TG];
+#pragma unroll
+                            for (int tt = 0; tt < TG; ++tt) d0[tt] = d1[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            // K steps in batches of 8: the batch's operand loads (8 per tile from L1 / L2, 8 from LDS) are all
+                            // in flight before its first matrix instruction; steps past the matrix get zero operands
                             for (int j0 = 0; j0 < ks; j0 += 8) {
-                                float bv[8], av[8];
+                                float bv[TG][8], av[8];
 #pragma unroll
-                                for (int u = 0; u < 8; ++u) {
-                                    const bool in = j0 + u < ks;
-                                    bv[u] = in ? bp[(j0 + u) * 64] : 0.f;
-                                    av[u] = arow[in ? 4 * (j0 + u) : 0];
-                                }
+                                for (int u = 0; u < 8; ++u) av[u] = arow[j0 + u < ks ? 4 * (j0 + u) : 0];
 #pragma unroll
-                                for (int u = 0; u < 8; u += 2) {
-                                    d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], d0, 0, 0, 0);
-                                    d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], d1, 0, 0, 0);
+                                for (int tt = 0; tt < TG; ++tt)
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u)
+                                        bv[tt][u] = (tt < nt && j0 + u < ks) ? bp[((int64_t)tt * ks + j0 + u) * 64] : 0.f;
+#pragma unroll
+                                for (int tt = 0; tt < TG; ++tt) {
+                                    if (tt >= nt) break;
+#pragma unroll
+                                    for (int u = 0; u < 8; u += 2) {
+                                        d0[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[tt][u], d0[tt], 0, 0, 0);
+                                        d1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[tt][u + 1], d1[tt], 0, 0, 0);
+                                    }
                                 }
                             }
-                            const int col = 16 * t + n;
-                            if (gi < gcount && col < p.cols) orow[col] = d0[0] + d1[0];
+#pragma unroll
+                            for (int tt = 0; tt < TG; ++tt) {
+                                const int col = 16 * (t0 + tt) + n;
+                                if (tt < nt && gi < gcount && col < p.cols) orow[col] = d0[tt][0] + d1[tt][0];
+                            }
                         }
                     } else { // no DCT: the log mel energies are the features
                         for (int g = 0; g < gcount; ++g)
