@@ -1311,7 +1311,8 @@ __device__ __forceinline__ void stockham_pass(float2 *buf, const float2 *s_tw, i
     wave_sync();
 }
 
-// HALF: the window is at most M samples (a short window zero padded to the transform, BASELINE configs[2]): the
+// HALF: a short window zero padded to the transform -- at most M samples at 1024 points (BASELINE configs[2]), at most
+// 1280 at 2048 points (25 ms at 44.1 kHz, configs[4]: 10 of the 16 rows of sample pairs): the
 // upper half of every lane's sample pairs is zero at compile time and pass 1 sheds the arithmetic on it.
 template <int LOG2M, bool FUSED, bool PAIR, bool HALF>
 __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? MFX_REG10_THREADS : 1024) k_front_reg(FrontParams p)
@@ -1389,10 +1390,13 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
         for (int k = 1; k < R2; ++k) tw2[k - 1] = s_tw[NT1 + (k - 1) * (M / (R1 * R2)) + lane / R1];  // W_(M/R1)^(pp k), pp = lane / R1
     }
     const int ch_n = p.channels, W = p.window_size;
-    // PREFETCH: the raw samples of the NEXT frame (one 32-bit word per sample pair) are requested while this frame's mel
-    // stage runs, so their latency never shows.
-    constexpr int NJ = HALF ? NV / 2 : NV;   // sample pairs per lane that can carry window taps
-    uint32_t raw[NJ];
+    // PREFETCH: the raw samples of the NEXT frame are requested while this frame's mel stage runs, so their latency never
+    // shows: the builds that load one 32-bit word per sample pair, and the short-window 2048-point stereo / odd-offset
+    // build (two words per pair, 10 rows: 20 registers -- with all 16 rows it spilled 71 registers, C5 1.18 ms against 1.02;
+    // the 1024-point stereo build has no registers left for it at 16 waves per CU).
+    constexpr int NJ = !HALF ? NV : LOG2M == 10 ? 10 : NV / 2;   // rows of 64 sample pairs that can carry window taps
+    constexpr bool PREFETCH = (PAIR && (FUSED || LOG2M == 9)) || (!PAIR && LOG2M == 10 && FUSED && HALF);
+    uint32_t raw[PAIR ? NJ : 2 * NJ];
     struct __attribute__((aligned(4))) Pair32 {
         uint32_t x, y;
     };
@@ -1401,13 +1405,24 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = lane + 64 * j;
-            raw[j] = 0u;
-            if (2 * n < W) raw[j] = ((const uint32_t *)(p.pcm + s0))[n];
+            if (PAIR) {
+                raw[j] = 0u;
+                if (2 * n < W) raw[j] = ((const uint32_t *)(p.pcm + s0))[n];
+            } else {
+                raw[2 * j] = raw[2 * j + 1] = 0u;
+                if (2 * n < W) {
+                    const bool has1 = 2 * n + 1 < W;
+                    if (ch_n == 2) { // (see the conversion below for the layouts)
+                        const Pair32 dd = *(const Pair32 *)((const uint32_t *)p.pcm + (s0 + 2 * n) - (has1 ? 0 : 1));
+                        raw[2 * j] = dd.x;
+                        raw[2 * j + 1] = dd.y;
+                    } else {
+                        raw[2 * j] = *(const u32_a2 *)(p.pcm + s0 + 2 * n - (has1 ? 0 : 1));
+                    }
+                }
+            }
         }
     };
-    // (only the builds that load one word per sample pair: the stereo / odd-offset builds hold two words per pair and
-    // have no registers to spare -- with the prefetch the 2048-point stereo build spilled 71 registers, 1.18 ms against 1.02)
-    constexpr bool PREFETCH = PAIR && (FUSED || LOG2M == 9);
     const int c_step = gridDim.x * n_waves;
     bool fetched = false; // raw holds the frame about to be worked on
     for (int c = blockIdx.x * n_waves + wave; c < p.n_chunks; c += c_step) {
@@ -1439,10 +1454,21 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
                     continue;
                 }
                 float x0 = 0.f, x1 = 0.f;
-                if (PREFETCH) { // (PAIR builds only)
+                if (PREFETCH && PAIR) {
                     const uint32_t d = raw[j];
                     x0 = (float)(int)(short)(d & 0xffffu);
                     x1 = (float)((int)d >> 16);
+                } else if (PREFETCH) { // (words past the window were set to zero)
+                    const bool has1 = 2 * n + 1 < W;
+                    if (ch_n == 2) {
+                        const uint32_t d0 = has1 ? raw[2 * j] : raw[2 * j + 1], d1 = raw[2 * j + 1];
+                        x0 = (float)(((int)(short)(d0 & 0xffffu) + ((int)d0 >> 16)) >> 1);
+                        if (has1) x1 = (float)(((int)(short)(d1 & 0xffffu) + ((int)d1 >> 16)) >> 1);
+                    } else {
+                        const uint32_t d = raw[2 * j];
+                        x0 = (float)(int)(short)(has1 ? (d & 0xffffu) : (d >> 16));
+                        if (has1) x1 = (float)((int)d >> 16);
+                    }
                 } else if (2 * n < W) { // loaded where it is consumed
                     if (PAIR) {
                         const uint32_t d = ((const uint32_t *)(p.pcm + s0))[n];
@@ -2109,12 +2135,12 @@ hipError_t launch_reg(const FrontParams &p, int nw, hipStream_t stream)
     const int per_cu = (int)((160 * 1024) / lds);
     const int cap = num_cus() * (per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu);
     if (blocks > cap) blocks = cap;
-    // the half-window build exists for 1024 points only (25 ms at 16 kHz zero padded to 1024: BASELINE configs[2])
-    if (LOG2M == 9 && p.window_size <= (1 << LOG2M)) {
-        constexpr bool H = LOG2M == 9;
+    // the short-window builds: 1024 points with at most 512 samples (25 ms at 16 kHz zero padded to 1024: BASELINE
+    // configs[2]), fused 2048 points with at most 1280 (25 ms at 44.1 kHz: configs[4])
+    constexpr bool H = LOG2M == 9 || (LOG2M == 10 && FUSED);
+    if (H && p.window_size <= (LOG2M == 9 ? 512 : 1280))
         return p.pair_ok ? launch_reg_inst<LOG2M, FUSED, true, H>(p, nw, lds, blocks, stream)
                          : launch_reg_inst<LOG2M, FUSED, false, H>(p, nw, lds, blocks, stream);
-    }
     return p.pair_ok ? launch_reg_inst<LOG2M, FUSED, true, false>(p, nw, lds, blocks, stream)
                      : launch_reg_inst<LOG2M, FUSED, false, false>(p, nw, lds, blocks, stream);
 }
