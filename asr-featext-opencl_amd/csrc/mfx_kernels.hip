@@ -1344,6 +1344,8 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
     float *s_wave = (float *)(s_mfid + 64 * rounds) + wave * (2 * MP + 4 * nbp);
     float2 *buf = (float2 *)s_wave;
     float *lm = s_wave + 2 * MP;                               // [4][nbp]
+    int *s_ctr = (int *)((float *)(s_mfid + 64 * rounds) + n_waves * (2 * MP + 4 * nbp)); // block-local work counter
+    if (tid == 0) *s_ctr = 0;
     (void)dl;
 
     const float scale = p.scale; // 0.5 / W2, a power of two: folded into the window taps (exact)
@@ -1423,15 +1425,34 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
             }
         }
     };
-    const int c_step = gridDim.x * n_waves;
+    // Block b owns chunks b, b + B, b + 2 B, ...; its waves draw from that list through a counter in LDS (as in
+    // k_front512), one draw ahead: waves that the SIMD arbiter favours take more chunks instead of finishing early, and
+    // the last chunks of the grid do not wait for one wave's fixed share (C3 0.313 -> 0.308 ms).  The 2048-point builds
+    // keep the fixed round-robin deal: they are at their register budget, and the draw's bookkeeping spilled 9 more
+    // registers there (C5 0.723 -> 0.759 ms).
+    constexpr bool DRAW = LOG2M != 10;
+    int fixed_c = blockIdx.x * n_waves + wave; // (!DRAW: wave w of the grid takes chunks w, w + W, w + 2 W, ...)
+    auto draw = [&]() -> int {
+        if (!DRAW) {
+            const int cc = fixed_c < p.n_chunks ? fixed_c : p.n_chunks;
+            if (fixed_c < p.n_chunks) fixed_c += gridDim.x * n_waves;
+            return cc;
+        }
+        int k = 0;
+        if ((tid & 63) == 0) k = __hip_atomic_fetch_add(s_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        k = __builtin_amdgcn_readfirstlane(k);
+        const long long cc = (long long)blockIdx.x + (long long)k * gridDim.x;
+        return cc < p.n_chunks ? (int)cc : p.n_chunks;
+    };
     bool fetched = false; // raw holds the frame about to be worked on
-    for (int c = blockIdx.x * n_waves + wave; c < p.n_chunks; c += c_step) {
+    int c = draw(), c_next = draw();
+    for (; c < p.n_chunks; c = c_next, c_next = draw()) {
         const Chunk ch = p.chunks[c];
         const int64_t rows_left = p.row_limit - ch.out_row;
         const int nf = (int)(rows_left < ch.n_frames ? (rows_left < 0 ? 0 : rows_left) : ch.n_frames);
         // the chunk after this one (its first frame is requested during this chunk's last)
-        const bool more = c + c_step < p.n_chunks;
-        const Chunk chn = p.chunks[more ? c + c_step : c];
+        const bool more = c_next < p.n_chunks;
+        const Chunk chn = p.chunks[more ? c_next : c];
         const int64_t rows_left_n = p.row_limit - chn.out_row;
         const bool next_has = more && chn.n_frames > 0 && rows_left_n > 0;
         for (int f = 0; f < nf; ++f) {
@@ -2082,7 +2103,7 @@ size_t front_reg_lds_floats(const FrontParams &p, bool fused, int n_waves)
 #else
     const size_t MP = M;
 #endif
-    f += (size_t)n_waves * (2 * MP + (fused ? 4 * lm_stride(p.num_banks) : 0));
+    f += (size_t)n_waves * (2 * MP + (fused ? 4 * lm_stride(p.num_banks) : 0)) + 4; // (+ the block's work counter)
     return f;
 }
 
