@@ -1391,6 +1391,12 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
 #pragma unroll
         for (int k = 1; k < R2; ++k) tw2[k - 1] = s_tw[NT1 + (k - 1) * (M / (R1 * R2)) + lane / R1];  // W_(M/R1)^(pp k), pp = lane / R1
     }
+    constexpr bool META_REG = FUSED && LOG2M == 9; // (the 2048-point builds have no register to spare)
+    int mst0 = 0, mfid0 = -1, mst1 = 0, mfid1 = -1;
+    if (META_REG) {
+        if (rounds > 0) mst0 = s_mst[lane], mfid0 = s_mfid[lane];
+        if (rounds > 1) mst1 = s_mst[64 + lane], mfid1 = s_mfid[64 + lane];
+    }
     const int ch_n = p.channels, W = p.window_size;
     // PREFETCH: the raw samples of the NEXT frame are requested while this frame's mel stage runs, so their latency never
     // shows: the builds that load one 32-bit word per sample pair, and the short-window 2048-point stereo / odd-offset
@@ -1588,10 +1594,9 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
                 {
                     float *lmf = lm + (f & 3) * nbp;
                     const float *wrow = s_mw + lane * RS;
-                    for (int r = 0; r < rounds; ++r) {
+                    auto one_round = [&](int r, int st, int fid) {
                         const int L = p.mel64_L[r];
-                        const float *mg = mag + s_mst[r * 64 + lane];
-                        const int fid = s_mfid[r * 64 + lane];
+                        const float *mg = mag + st;
                         float acc = 0.f;
                         for (int s2 = 0; s2 < L; s2 += 8) {
                             const float4 w0 = lds_read_b128((const float4 *)(wrow + s2));
@@ -1610,7 +1615,16 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
                         }
                         wrow += L;
                         lmf[fid >= 0 ? fid : nbp - 1] = MFX_LOG(fmaxf(acc, 1e-30f)); // idle lane: the row's spare word
+                    };
+                    // (META_REG: the first two rounds' starts / filter ids wait in registers -- one dependent LDS round trip
+                    // less per round; the waves are bound by the number of those, not by LDS bytes)
+                    int r = 0;
+                    if (META_REG) {
+                        if (rounds > 0) one_round(0, mst0, mfid0);
+                        if (rounds > 1) one_round(1, mst1, mfid1);
+                        r = 2;
                     }
+                    for (; r < rounds; ++r) one_round(r, s_mst[r * 64 + lane], s_mfid[r * 64 + lane]);
                 }
                 wave_sync();
                 // ---- every 4th frame (and at the chunk's end): DCT-II + lifter of the waiting frames on the matrix pipe,
