@@ -64,11 +64,13 @@ struct mfx_handle {
     int spec_pitch = 0;
     int channels = 1;
     bool fast512 = false;
+    bool fast1024 = false; // 1024 points, window <= 512 samples: k_front1024 (two 256-point transforms per frame)
     int nm16 = 16;
     float alpha = 1.f, table_alpha = -1.f;
     bool have_window = false;
 
     // tables in HBM
+    DevBuf<float> d_win1024o;
     DevBuf<float> d_window, d_winpair, d_twid_pass, d_twid_half, d_twid_split, d_twid_reg, d_mel_w, d_dct;
     DevBuf<int32_t> d_mel_beg, d_mel_items, d_mel_pieces;
     DevBuf<float> d_mel_item_w, d_sweep_item_w;
@@ -216,6 +218,18 @@ int refresh_mel(mfx_handle *h)
         fill_front(h, probe);
         h->fused_ok = front512_lds_bytes(probe) <= 160 * 1024;
     }
+    if (h->fast1024) {
+        // bins up to 527 may be read (times zero weights): the slot keeps 264 words for each of the even / odd arrays
+        h->fused_ok = false;
+        if (build_mel_lane_plan(t, h->nb, h->W2, /*max_read_bin=*/527, h->plan, /*align=*/4)) {
+            HIP_TRY(h, upload(h->d_mel_lane_w, h->plan.w));
+            HIP_TRY(h, upload(h->d_mel_lane_start, h->plan.start));
+            HIP_TRY(h, upload(h->d_mel_lane_fid, h->plan.fid));
+            FrontParams probe;
+            fill_front(h, probe);
+            h->fused_ok = front1024_lds_bytes(probe) <= 160 * 1024;
+        }
+    }
     h->wplan_ok = false;
     if (h->W2 >= 1024 && h->W2 <= 2048) { // the fused long-transform kernel walks the filters on the frame's 64 lanes
         const int M = h->W2 / 2, MP = M; // floats of the wave's complex buffer = 2 MP (k_front_reg)
@@ -240,6 +254,7 @@ void fill_front(const mfx_handle *h, FrontParams &p)
     p.fft_size = h->W2;
     p.window = h->d_window.p;
     p.winpair = h->d_winpair.p;
+    p.win1024o = h->d_win1024o.p;
     p.twid_pass = h->d_twid_pass.p;
     p.twid_half = h->d_twid_half.p;
     p.twid_reg = h->d_twid_reg.p;
@@ -383,6 +398,7 @@ extern "C" void mfx_destroy(mfx_handle *h)
     }
     h->d_window.release();
     h->d_winpair.release();
+    h->d_win1024o.release();
     h->d_twid_pass.release();
     h->d_twid_half.release();
     h->d_twid_reg.release();
@@ -508,6 +524,10 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
     h->spec_pitch = ((h->W2 / 2 + 1) + 3) & ~3;
     h->fast512 = front512_supported(h->W2, h->W, h->nb, h->cols, h->channels);
     {
+        const char *e = std::getenv("MFX_NO_FRONT1024"); // dev: keep k_front_reg for such configurations
+        h->fast1024 = !(e && e[0] == '1') && front1024_supported(h->W2, h->W, h->nb, h->cols, h->channels, h->ceps);
+    }
+    {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, hip_device) == hipSuccess && prop.multiProcessorCount > 0)
             h->num_cus = prop.multiProcessorCount;
@@ -560,7 +580,7 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
                 }
             if (upload(h->d_twid_reg, reg) != hipSuccess) return bail(MFX_ERR_DEVICE);
         }
-        if (h->fast512) {
+        if (h->fast512 || h->fast1024) {
             std::vector<float> full;
             build_twiddles(256, 256, full); // W_256^e
             std::vector<float> pass(16 * 16 * 2);
@@ -705,7 +725,7 @@ extern "C" int mfx_profile_read(mfx_handle *h, int32_t *launches, double *kernel
 extern "C" const char *mfx_dominant_kernel_name(const mfx_handle *h)
 {
     if (!h) return "";
-    return h->fast512 ? "k_front512" : h->W2 >= 1024 ? "k_front_reg" : "k_front_wave"; // names as rocprofv3 prints them
+    return h->fast512 ? "k_front512" : (h->fast1024 && h->fused_ok) ? "k_front1024" : h->W2 >= 1024 ? "k_front_reg" : "k_front_wave"; // names as rocprofv3 prints them
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -721,7 +741,28 @@ extern "C" int mfx_set_window(mfx_handle *h, const float *window)
     std::memcpy(padded.data(), window, sizeof(float) * h->W);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, upload(h->d_window, padded));
-    if (h->fast512) {
+    if (h->fast1024) {
+        // phase O of k_front1024: (taps of pair n) x W_512^n as the real 2 x 2 form
+        //   re = A x0 + B x1,  im = C x0 + D x1,   (A, B, C, D) = (t0 c, -t1 s, t0 s, t1 c),  W_512^n = c + i s
+        // with the same output scale folded in (exact: a power of two)
+        const float fold = 0.5f / (float)h->W2;
+        std::vector<float> tw512;
+        build_twiddles(512, 256, tw512);
+        std::vector<float> wo(16 * 16 * 4, 0.f);
+        for (int l = 0; l < 16; ++l)
+            for (int m = 0; m < 16; ++m) {
+                const int n = l + 16 * m;
+                const float t0 = padded[2 * n] * fold, t1 = padded[2 * n + 1] * fold;
+                const float c = tw512[2 * n], sn = tw512[2 * n + 1];
+                float *q = &wo[4 * (l * 16 + m)];
+                q[0] = t0 * c;
+                q[1] = -(t1 * sn);
+                q[2] = t0 * sn;
+                q[3] = t1 * c;
+            }
+        HIP_TRY(h, upload(h->d_win1024o, wo));
+    }
+    if (h->fast512 || h->fast1024) {
         // The 512-point kernel's copy carries the output scale 0.5 / W2 (1/2 of the real split, 1/W2 of
         // mfcccpu.cpp:203).  It is a power of two, so scaling the taps instead of the magnitudes changes no
         // bit of the result (every intermediate is the same value times 2^-10) and saves a multiply per bin.
@@ -1405,7 +1446,7 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
     // chunks a wave can sit idle for most of a chunk time (~34 us on C2) at the end of the launch.  The last two
     // chunks of every wave of the grid are therefore cut into 4-frame pieces (one kernel iteration each).
     const char *ts = std::getenv("MFX_TAIL_SPLIT");
-    if (h->fast512 && !(ts && ts[0] == '0')) {
+    if ((h->fast512 || (h->fast1024 && h->fused_ok)) && !(ts && ts[0] == '0')) {
         const size_t n = h->h_chunks.size();
         const size_t tail = std::min<size_t>(n, (size_t)(ts && ts[0] > '0' ? ts[0] - '0' : 2) * 16 * h->num_cus);
         if (n >= 4 * tail) { // only when the launch is long enough for the tail to matter
@@ -1495,9 +1536,10 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
     // Which front end: the 512-point register kernel, else the fused wave-per-frame kernel when its
     // LDS fits, else spectrum through an HBM slab + melcep.
     const bool fused512 = h->fast512 && h->fused_ok;
+    const bool fused1024 = h->fast1024 && h->fused_ok;
     // (up to 2048 points the fused form saves the spectrum's round trip through HBM -- 8 KB per frame at 2048
     // points; at 4096 points the tables + per-wave buffers no longer leave enough waves per CU)
-    const bool fusedgen = !fused512 && h->W2 <= 2048 && (h->W2 < 1024 || h->wplan_ok) &&
+    const bool fusedgen = !fused512 && !fused1024 && h->W2 <= 2048 && (h->W2 < 1024 || h->wplan_ok) &&
                           front_wave_lds_bytes(p, true) <= 160 * 1024;
     // With deltas on, the front end writes its statics as compact 64-byte rows into a scratch buffer
     // and the delta kernel emits whole [static | d | dd] rows: every HBM write is then a full line
@@ -1507,7 +1549,7 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
     // event, so the memory-bound tail of batch i shares the GPU with the compute-bound front end of
     // batch i+1; the statics scratch is double buffered and the front end of batch i+2 waits for tail i.
     const int sb = (h->overlap && whole) ? (int)(h->batch_seq & 1) : 0;
-    const bool via_scratch = ((fused512 && p.dct_mode == 1) || fusedgen) && h->l1 > 0 && h->cols <= 16 && !norm_before &&
+    const bool via_scratch = ((fused512 && p.dct_mode == 1) || fused1024 || fusedgen) && h->l1 > 0 && h->cols <= 16 && !norm_before &&
                              h->d_static16[sb].n >= (size_t)h->total_rows * 16;
     // Fused delta stage: the 512-point kernel's last wave per block turns the statics into whole output
     // rows while the other 15 produce them; no separate delta launch.
@@ -1543,6 +1585,9 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
         p.spec = h->d_spec.p; // unused by the fused kernel; a -DMFX_STAMPS dev build drops its cycle sums here
         ProfScope ps(h);
         HIP_TRY(h, launch_front512(p, /*to_spectrum=*/false, h->batch_aligned, h->nm16, h->stream));
+    } else if (fused1024) {
+        ProfScope ps(h);
+        HIP_TRY(h, launch_front1024(p, h->batch_aligned, h->nm16, h->stream));
     } else if (fusedgen) {
         ProfScope ps(h);
         HIP_TRY(h, launch_front_generic(p, /*fused=*/true, h->stream));

@@ -63,7 +63,8 @@ struct FrontParams {
     int32_t feat_pitch;
     // tables (device pointers)
     const float *window;      // [W2] zero padded                      (generic)
-    const float *winpair;     // [16][16][2] window laid out per lane  (512 fast path)
+    const float *winpair;     // [16][16][2] window laid out per lane  (512 fast path, k_front1024 phase E)
+    const float *win1024o;    // [16][16][4] window x W_512^m as (A, B, C, D) per sample pair (k_front1024 phase O)
     const float *twid_pass;   // [16][16][2] W_256^(l*k)               (512 fast path)
     const float *twid_half;   // [W2/2][2]   W_{W2/2}^k, k < W2/2       (generic Stockham, radix 4 needs 3k)
     const float *twid_reg;    // k_front_reg: pass tables [R1-1][M/R1][2] then [R1-1][M/R1^2][2] (W2 >= 1024)
@@ -189,6 +190,11 @@ size_t front512_lds_bytes(const FrontParams &p);
 
 // true when the 512-point fast path can take this configuration
 bool front512_supported(int fft_size, int window_size, int num_banks, int cols, int channels);
+// k_front1024: 1024-point transform of a window of at most 512 samples on the k_front512 core (two 256-point complex
+// transforms per frame: even and odd bins), mel -> log -> DCT fused, statics out
+bool front1024_supported(int fft_size, int window_size, int num_banks, int cols, int channels, int ceps_len);
+size_t front1024_lds_bytes(const FrontParams &p);
+hipError_t launch_front1024(const FrontParams &p, bool aligned, int nm16, hipStream_t stream);
 
 // symbol name of the dominant kernel for rocprofv3 (depends on the instantiation chosen)
 const char *front512_kernel_name(bool to_spectrum, bool aligned, int nm16);

@@ -259,6 +259,12 @@ __device__ __forceinline__ float row_partner_own0(float own, float x)
     return __int_as_float(t);
 }
 
+// x of lane 15 - l of the same 16-lane row
+__device__ __forceinline__ float row_mirror(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, true));
+}
+
 template <bool ALIGNED, int NM>
 struct PcmRegs {
     uint32_t d[ALIGNED ? NM : 2 * NM];
@@ -1037,6 +1043,336 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
         for (int i = 0; i < 8; ++i) o[i] = st_acc[i];
     }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_front1024: the 1024-point transform of a window of at most 512 samples (25 ms at 16 kHz zero padded to 1024:
+// BASELINE configs[2]) on the k_front512 core -- 4 frames per wave iteration, 16 lanes per frame, ONE LDS transpose
+// per 256-point complex transform -- instead of k_front_reg's wave per frame with three LDS passes (whose waves are
+// bound by the number of dependent LDS round trips per frame).
+//
+// With x[n] = 0 for n >= 512 the 1024-point DFT splits by decimation in frequency over the SAME packed samples
+// z[m] = x[2m] + i x[2m+1], m < 256:
+//   even bins  X[2k]   = the 512-point real DFT of x = FFT256(z) + the twiddled split of k_front512 (phase E);
+//   odd bins   X[2k+1] = U0[k] + W_1024^(2k+1) U1[k],  U_s = FFT256(x[2m+s] W_512^m):  V = FFT256(z W_512^m) = U0 + i U1
+//              and conj U_s[k] = U_s[255-k], so with S = V[k] + conj V[255-k], D = V[k] - conj V[255-k],
+//              T = (-i W_1024^(2k+1)) D:   X[2k+1] = (S + T) / 2,   X[2(255-k)+1] = conj(S - T) / 2          (phase O)
+// -- the same split arithmetic with another twiddle and the partner in lane 15 - l, register 15 - p (a plain row mirror,
+// no self-paired bins).  Phase O multiplies the samples by the window taps times W_512^m (a 2 x 2 real table per sample
+// pair) and runs first; its 16 magnitudes per lane wait in registers while phase E re-converts the same raw words.
+// Magnitudes land de-interleaved in the frame's slot (E[i] = bin 2i, O[i] = bin 2i+1); the mel walk reads two bins of
+// each per 8-byte read and adds them in ascending bin order (mfcccpu.cpp:192-220); log, DCT on the matrix pipe as in
+// k_front512 (20 K steps: at most 80 filters).
+// ------------------------------------------------------------------------------------------------
+constexpr int kWavesL = 12;       // waves per block = per CU (3 per SIMD: 168 registers)
+constexpr int kSlotL = 672;       // dwords per frame slot: [0, 512) transposes, then E | O magnitudes (2 x 264); log energies
+                                  // from 528 (672 = 32 mod 64: neighbouring slots sit on complementary bank halves)
+constexpr int kOddOffL = 264;     // O magnitudes inside the slot
+constexpr int kMelOffL = 528;
+constexpr int kTabStrideO = 68;   // dwords per lane row of the phase-O window table (16 x (A, B, C, D) + pad: 17 16-byte words)
+constexpr int kDctStepsL = 20;    // num_banks <= 80
+constexpr int kDctRowL = 20;      // dwords per lane row of the B operand table (5 16-byte words: odd)
+
+template <bool ALIGNED, int NM>
+__global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int slot = lane >> 4, l = lane & 15;
+    const int cols = p.cols, rounds = p.mel_rounds, RS = p.mel_row_stride;
+
+    float *s_win = smem;                               // [16 l][kTabStride]: E window pairs (w[2n], w[2n+1]) * 0.5 / W2
+    float *s_winO = s_win + 16 * kTabStride;           // [16 l][kTabStrideO]: (A, B, C, D) of pair n = l + 16 m
+    float *s_tw = s_winO + 16 * kTabStrideO;           // [16 l][kTabStride]: W_256^(l k)
+    float *s_splitE = s_tw + 16 * kTabStride;          // [16 l][kSplitStride]: -i W_1024^(2 (l + 16 p))
+    float *s_splitO = s_splitE + 16 * kSplitStride;    // [16 l][kSplitStride]: -i W_1024^(2 (l + 16 p) + 1)
+    float *s_melw = s_splitO + 16 * kSplitStride;      // [16][RS]
+    int *s_mstart = (int *)(s_melw + 16 * RS);         // [rounds][16]
+    int *s_mfid = s_mstart + 16 * rounds;              // [rounds][16]
+    float *s_dct = (float *)(s_mfid + 16 * rounds);    // [64][kDctRowL]: matrix-pipe B operands per lane
+    float *s_wave = s_dct + 64 * kDctRowL + wave * (4 * kSlotL);
+    float *xb = s_wave + slot * kSlotL;
+    int *s_ctr = (int *)(s_dct + 64 * kDctRowL + kWavesL * (4 * kSlotL));
+    if (tid == 0) *s_ctr = 0;
+
+    for (int i = tid; i < 256; i += kWavesL * 64) { // HBM tables are [lane][m]
+        ((float2 *)(s_win + (i >> 4) * kTabStride))[i & 15] = ((const float2 *)p.winpair)[i];
+        ((float4 *)(s_winO + (i >> 4) * kTabStrideO))[i & 15] = ((const float4 *)p.win1024o)[i];
+        ((float2 *)(s_tw + (i >> 4) * kTabStride))[i & 15] = ((const float2 *)p.twid_pass)[i];
+    }
+    for (int i = tid; i < 128; i += kWavesL * 64) { // twid_split holds -i W_1024^e, e <= 512, in natural order
+        ((float2 *)(s_splitE + (i & 15) * kSplitStride))[i >> 4] = ((const float2 *)p.twid_split)[2 * i];
+        ((float2 *)(s_splitO + (i & 15) * kSplitStride))[i >> 4] = ((const float2 *)p.twid_split)[2 * i + 1];
+    }
+    for (int i = tid; i < 16 * RS; i += kWavesL * 64) s_melw[i] = p.mel_lane_w[i];
+    for (int i = tid; i < 16 * rounds; i += kWavesL * 64) {
+        s_mstart[i] = p.mel_lane_start[i];
+        s_mfid[i] = p.mel_lane_fid[i];
+    }
+    for (int i = tid; i < 64 * kDctRowL; i += kWavesL * 64) {
+        const int ln = i / kDctRowL, j = i - ln * kDctRowL, m = 4 * j + (ln >> 4), n = ln & 15;
+        s_dct[i] = (m < p.num_banks && n < p.dct_len) ? p.dct[m * p.dct_len + n] : 0.f;
+    }
+    for (int i = lane; i < 4 * kSlotL; i += 64) s_wave[i] = 0.f; // words read before they are written meet zero weights: finite
+    __syncthreads();
+
+    // ---- chunk walk: as k_front512 (descriptor per chunk, software pipelined, block-local work counter)
+    struct ChunkCtx {
+        int64_t out_row;
+        int n_live, odd0;
+        __amdgpu_buffer_rsrc_t rsrc;
+    };
+    auto make_ctx = [&](int c) -> ChunkCtx {
+        ChunkCtx x;
+        const bool valid = c < p.n_chunks;
+        const Chunk *chp = p.chunks + (valid ? c : 0);
+        const int64_t pcm_off = chp->pcm_off;
+        x.out_row = chp->out_row;
+        const int n_frames = valid ? chp->n_frames : 0;
+        const int64_t rows_left = p.row_limit - x.out_row;
+        x.n_live = (int)(rows_left < n_frames ? (rows_left < 0 ? 0 : rows_left) : n_frames);
+        const int64_t base_s = ALIGNED ? pcm_off : (pcm_off & ~(int64_t)1);
+        x.odd0 = ALIGNED ? 0 : (int)(pcm_off & 1);
+        int64_t bytes_left = valid ? (((p.pcm_total - base_s) * 2 + 3) & ~(int64_t)3) : 0; // (whole words: see k_front512)
+        if (bytes_left > 0xfffffff0ll) bytes_left = 0xfffffff0ll;
+        if (bytes_left < 0) bytes_left = 0;
+        const uintptr_t bp = (uintptr_t)(p.pcm + base_s);
+        const uint32_t bp_lo = __builtin_amdgcn_readfirstlane((uint32_t)bp);
+        const uint32_t bp_hi = __builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32));
+        const uint32_t nbytes = __builtin_amdgcn_readfirstlane((uint32_t)bytes_left);
+        x.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(((uintptr_t)bp_hi << 32) | bp_lo), 0, nbytes, 0x00020000);
+        return x;
+    };
+    auto lane_off = [&](const ChunkCtx &x, int f) -> int {
+        const int s = x.odd0 + f * p.shift + 2 * l;
+        return ALIGNED ? s * 2 : (s & ~1) * 2;
+    };
+    auto next_index = [&]() -> int {
+        int k = 0;
+        if (lane == 0) k = __hip_atomic_fetch_add(s_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return k;
+    };
+    auto chunk_of = [&](int k) -> int {
+        const long long c = (long long)blockIdx.x + (long long)k * gridDim.x;
+        return c < p.n_chunks ? (int)c : p.n_chunks;
+    };
+    int v_a = next_index(), v_b = next_index(), v_nn = next_index();
+    int c_cur = chunk_of(__builtin_amdgcn_readfirstlane(v_a));
+    int c_nxt = chunk_of(__builtin_amdgcn_readfirstlane(v_b));
+    ChunkCtx ccur = make_ctx(c_cur);
+    ChunkCtx cnxt = make_ctx(c_nxt);
+    PcmRegs<ALIGNED, NM> cur;
+    pcm_issue<ALIGNED, NM>(cur, ccur.rsrc, lane_off(ccur, slot));
+
+    while (c_cur < p.n_chunks) {
+        const int64_t out_row = ccur.out_row;
+        const int n_live = ccur.n_live;
+        const int odd0 = ccur.odd0;
+        for (int f0 = 0; f0 < n_live; f0 += 4) {
+            const int f = f0 + slot;
+            const bool live = f < n_live;
+            const bool last = f0 + 4 >= n_live;
+            const bool odd = !ALIGNED && ((odd0 + f * p.shift) & 1);
+            // sample pair m of this lane (n = l + 16 m) as two floats, from the raw words
+            auto pair_of = [&](int m, float &x0, float &x1) {
+                uint32_t d;
+                if (ALIGNED) {
+                    d = cur.d[m];
+                } else {
+                    const uint32_t d0 = cur.d[2 * m], d1 = cur.d[2 * m + 1];
+                    d = odd ? ((d0 >> 16) | (d1 << 16)) : d0;
+                }
+                x0 = (float)(int)(short)(d & 0xffffu);
+                x1 = (float)((int)d >> 16);
+            };
+            // pass A + inter-pass twiddle + 16 x 16 transpose through the slot + pass B: a[pp] = FFT256(a)[l + 16 pp]
+            auto fft256 = [&](float2(&a)[16]) {
+                fft16(a);
+                {
+                    float4 tq[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) tq[k] = lds_read_b128((const float4 *)(s_tw + l * kTabStride) + k);
+#pragma unroll
+                    for (int k = 0; k < 16; k += 2) {
+                        const float4 t = tq[k >> 1];
+                        if (k > 0) a[k] = cmul(a[k], make_float2(t.x, t.y));
+                        a[k + 1] = cmul(a[k + 1], make_float2(t.z, t.w));
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) ((float2 *)(xb + k * 32))[l ^ (k & 14)] = a[k];
+                wave_sync();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 v = ((const float4 *)(xb + l * 32))[j ^ (l >> 1)];
+                    a[2 * j] = make_float2(v.x, v.y);
+                    a[2 * j + 1] = make_float2(v.z, v.w);
+                }
+                wave_sync();
+                fft16(a);
+            };
+
+            // ---- phase O: odd bins
+            float magO_k[8], magO_p[8];
+            {
+                float2 a[16];
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    if (m < NM) {
+                        float x0, x1;
+                        pair_of(m, x0, x1);
+                        const float4 t = ((const float4 *)(s_winO + l * kTabStrideO))[m];
+                        a[m] = make_float2(t.x * x0 + t.y * x1, t.z * x0 + t.w * x1);
+                    } else {
+                        a[m] = make_float2(0.f, 0.f);
+                    }
+                }
+                fft256(a);
+                float4 csq[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) csq[j] = ((const float4 *)(s_splitO + l * kSplitStride))[j];
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) {
+                    // partner V[255 - k]: register 15 - pp of lane 15 - l
+                    const float zr = row_mirror(a[15 - pp].x);
+                    const float zi = row_mirror(a[15 - pp].y);
+                    const float2 cs = (pp & 1) ? make_float2(csq[pp >> 1].z, csq[pp >> 1].w) : make_float2(csq[pp >> 1].x, csq[pp >> 1].y);
+                    const float sr = a[pp].x + zr, si = a[pp].y - zi;
+                    const float dr = a[pp].x - zr, di = a[pp].y + zi;
+                    const float tr = cs.x * dr - cs.y * di;
+                    const float ti = cs.x * di + cs.y * dr;
+                    const float xr = sr + tr, xi = si + ti;
+                    const float yr = sr - tr, yi = si - ti;
+                    magO_k[pp] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi); // the window taps carry 0.5 / W2
+                    magO_p[pp] = __builtin_amdgcn_sqrtf(yr * yr + yi * yi);
+                }
+            }
+
+            // ---- phase E: even bins = k_front512's transform of the same samples
+            float magE_k[8], magE_p[8], magE128;
+            {
+                float2 a[16];
+                float4 wq[(NM + 1) / 2];
+#pragma unroll
+                for (int m = 0; m < (NM + 1) / 2; ++m) wq[m] = ((const float4 *)(s_win + l * kTabStride))[m];
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    if (m < NM) {
+                        float x0, x1;
+                        pair_of(m, x0, x1);
+                        const float2 w = (m & 1) ? make_float2(wq[m >> 1].z, wq[m >> 1].w) : make_float2(wq[m >> 1].x, wq[m >> 1].y);
+                        a[m] = make_float2(w.x * x0, w.y * x1);
+                    } else {
+                        a[m] = make_float2(0.f, 0.f);
+                    }
+                }
+                // the raw words are consumed: prefetch the next 4 frames (of this chunk, or the first of the next chunk)
+                pcm_issue<ALIGNED, NM>(cur, last ? cnxt.rsrc : ccur.rsrc, last ? lane_off(cnxt, slot) : lane_off(ccur, f + 4));
+                fft256(a);
+                const float m128r = a[8].x + a[8].x, m128i = a[8].y + a[8].y;
+                magE128 = __builtin_amdgcn_sqrtf(m128r * m128r + m128i * m128i);
+                float4 csq[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) csq[j] = ((const float4 *)(s_splitE + l * kSplitStride))[j];
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) {
+                    const float zr = row_partner_own0(a[(16 - pp) & 15].x, a[15 - pp].x);
+                    const float zi = row_partner_own0(a[(16 - pp) & 15].y, a[15 - pp].y);
+                    const float2 cs = (pp & 1) ? make_float2(csq[pp >> 1].z, csq[pp >> 1].w) : make_float2(csq[pp >> 1].x, csq[pp >> 1].y);
+                    const float sr = a[pp].x + zr, si = a[pp].y - zi;
+                    const float dr = a[pp].x - zr, di = a[pp].y + zi;
+                    const float tr = cs.x * dr - cs.y * di;
+                    const float ti = cs.x * di + cs.y * dr;
+                    const float xr = sr + tr, xi = si + ti;
+                    const float yr = sr - tr, yi = si - ti;
+                    magE_k[pp] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
+                    magE_p[pp] = __builtin_amdgcn_sqrtf(yr * yr + yi * yi);
+                }
+            }
+
+            // ---- magnitudes to the slot: E[i] = |X[2 i]|, i <= 256; O[i] = |X[2 i + 1]|, i < 256
+            {
+                float *elo = xb + l, *ehi = xb + (144 - l);                        // i = l + 16 p and 256 - l - 16 p
+                float *olo = xb + kOddOffL + l, *ohi = xb + kOddOffL + (143 - l);   // i = l + 16 p and 255 - l - 16 p
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) elo[16 * pp] = magE_k[pp];
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) ehi[16 * pp] = magE_p[7 - pp];
+                if (l == 0) xb[128] = magE128;
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) olo[16 * pp] = magO_k[pp];
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) ohi[16 * pp] = magO_p[7 - pp];
+            }
+            wave_sync();
+
+            // ---- mel filterbank: per round every lane walks one filter's bins in ascending order
+            // (mfcccpu.cpp:192-220); starts are multiples of 4 bins: two even and two odd bins per 8-byte read
+            const float *wrow = s_melw + l * RS;
+            float *dst = p.feat + (out_row + f0) * (int64_t)p.feat_pitch + slot * p.feat_pitch;
+            float *lm = xb + kMelOffL + 8 * slot;
+            for (int r = 0; r < rounds; ++r) {
+                const int L = p.mel_L[r];
+                const int st = s_mstart[r * 16 + l] >> 1;
+                const float *me = xb + st, *mo = xb + kOddOffL + st;
+                const int fid = s_mfid[r * 16 + l];
+                float acc = 0.f;
+                for (int s = 0; s < L; s += 8) {
+                    float4 w[2];
+                    float2 e[2], o[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) w[q] = *(const float4 *)(wrow + s + 4 * q);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        e[q] = lds_read_b64((const float2 *)(me + (s >> 1) + 2 * q));
+                        o[q] = lds_read_b64((const float2 *)(mo + (s >> 1) + 2 * q));
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        acc += w[q].x * e[q].x;
+                        acc += w[q].y * o[q].x;
+                        acc += w[q].z * e[q].y;
+                        acc += w[q].w * o[q].y;
+                    }
+                }
+                wrow += L;
+                lm[fid >= 0 ? fid : 4 * kDctStepsL] = MFX_LOG(fmaxf(acc, 1e-30f)); // idle lane: a word nobody reads
+            }
+            wave_sync();
+            // ---- DCT-II + lifter on the matrix pipe (see k_front512): frame `slot` in rows 4 slot .. 4 slot + 3
+            {
+                const float *arow = s_wave + (l >> 2) * (kSlotL + 8) + kMelOffL + slot;
+                const float4 *bq = (const float4 *)(s_dct + lane * kDctRowL);
+                float dctb[kDctStepsL];
+#pragma unroll
+                for (int j = 0; j < kDctStepsL / 4; ++j) {
+                    const float4 t = bq[j];
+                    dctb[4 * j] = t.x;
+                    dctb[4 * j + 1] = t.y;
+                    dctb[4 * j + 2] = t.z;
+                    dctb[4 * j + 3] = t.w;
+                }
+                f32x4 dacc = {0.f, 0.f, 0.f, 0.f}, dacc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < kDctStepsL; j += 2) {
+                    dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * j], dctb[j], dacc, 0, 0, 0);
+                    dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * j + 4], dctb[j + 1], dacc2, 0, 0, 0);
+                }
+                const float outv = dacc[0] + dacc2[0];
+                if (live && (l < cols || p.feat_pitch == 16)) dst[l] = outv;
+            }
+            wave_sync();
+        }
+        if (n_live <= 0) pcm_issue<ALIGNED, NM>(cur, cnxt.rsrc, lane_off(cnxt, slot)); // empty chunk: nothing was prefetched
+        c_cur = c_nxt;
+        ccur = cnxt;
+        asm volatile("" : "+v"(v_nn));
+        c_nxt = chunk_of(__builtin_amdgcn_readfirstlane(v_nn));
+        cnxt = make_ctx(c_nxt);
+        v_nn = next_index();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2066,6 +2402,46 @@ hipError_t launch512(const FrontParams &p_in, hipStream_t stream)
 }
 
 } // namespace
+
+size_t front1024_lds_bytes(const FrontParams &p)
+{
+    size_t f = 2 * 16 * kTabStride + 16 * kTabStrideO + 2 * 16 * kSplitStride; // window pairs (E, O), pass twiddles, split twiddles (E, O)
+    f += (size_t)16 * p.mel_row_stride + (size_t)32 * p.mel_rounds;             // per-lane mel weights, bin starts + filter ids
+    f += (size_t)64 * kDctRowL;                                                 // matrix-pipe operands of the DCT
+    f += (size_t)kWavesL * 4 * kSlotL + 4;                                      // 4 frame slots per wave, work counter
+    return f * sizeof(float);
+}
+
+bool front1024_supported(int fft_size, int window_size, int num_banks, int cols, int channels, int ceps_len)
+{
+    return fft_size == 1024 && window_size > 0 && window_size <= 512 && channels <= 1 && num_banks >= 1 &&
+           num_banks <= 4 * kDctStepsL && cols <= 16 && ceps_len > 0;
+}
+
+namespace {
+template <bool A, int NM>
+hipError_t launch1024(const FrontParams &p, hipStream_t stream)
+{
+    const size_t lds = front1024_lds_bytes(p);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_front1024<A, NM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    int blocks = (p.n_chunks + kWavesL - 1) / kWavesL;
+    if (blocks > num_cus()) blocks = num_cus(); // one block of 12 waves per CU
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((k_front1024<A, NM>), dim3(blocks), dim3(kWavesL * 64), lds, stream, p);
+    return hipGetLastError();
+}
+} // namespace
+
+hipError_t launch_front1024(const FrontParams &p, bool aligned, int nm16, hipStream_t stream)
+{
+    if (p.n_chunks <= 0) return hipSuccess;
+    const bool nm13 = nm16 <= 13;
+    if (aligned) return nm13 ? launch1024<true, 13>(p, stream) : launch1024<true, 16>(p, stream);
+    return nm13 ? launch1024<false, 13>(p, stream) : launch1024<false, 16>(p, stream);
+}
 
 bool front512_supported(int fft_size, int window_size, int num_banks, int cols, int channels)
 {

@@ -109,7 +109,7 @@ static int stride_4odd(int n)
     return 4 * q;
 }
 
-bool build_mel_lane_plan(const MelTable &t, int num_banks, int fft_size, int max_read_bin, MelLanePlan &out)
+bool build_mel_lane_plan(const MelTable &t, int num_banks, int fft_size, int max_read_bin, MelLanePlan &out, int align)
 {
     std::vector<int> order(num_banks);
     for (int m = 0; m < num_banks; ++m) order[m] = m;
@@ -131,18 +131,18 @@ bool build_mel_lane_plan(const MelTable &t, int num_banks, int fft_size, int max
             if (idx >= num_banks) continue;
             const int m = order[idx];
             const int b0 = t.beg[m], b1 = t.beg[m + 2];
-            int start = b0 & ~1;
+            int start = b0 & ~(align - 1);
             // a few pairs early at most: a longer shift costs more in padded bins (every lane runs
             // the round's longest span) than the two-way bank conflict it would avoid
             for (int d = 0; d < 4; ++d) {
-                const int cand = (b0 & ~1) - 2 * d;
+                const int cand = (b0 & ~(align - 1)) - align * d;
                 if (cand < 0) break;
-                if (!used[(cand >> 1) & 15]) {
+                if (!used[(cand / align) & 15]) {
                     start = cand;
                     break;
                 }
             }
-            used[(start >> 1) & 15] = true;
+            used[(start / align) & 15] = true;
             out.start[r * 16 + j] = start;
             out.fid[r * 16 + j] = m;
             longest = std::max(longest, b1 - start);

@@ -56,7 +56,9 @@ struct MelLanePlan {
 
 // false when the plan does not fit the kernel's limits (more than 8 rounds, or a padded span that
 // would read past `max_read_bin`)
-bool build_mel_lane_plan(const MelTable &t, int num_banks, int fft_size, int max_read_bin, MelLanePlan &out);
+// align: starts are multiples of it (2: two bins per 8-byte read of one magnitude array; 4: the de-interleaved even / odd
+// arrays of k_front1024, two bins of each per 8-byte read)
+bool build_mel_lane_plan(const MelTable &t, int num_banks, int fft_size, int max_read_bin, MelLanePlan &out, int align = 2);
 
 // The same plan for the wave-per-frame kernels (64 lanes share a frame; k_front_reg): rounds of 64 filters, longest
 // first, every lane walks its filter's bins in ascending order (the reference's summation order, mfcccpu.cpp:192-220).
