@@ -431,6 +431,75 @@ def test_c3_shape_1024_override(pkg, orc, W, S, off):
     assert_close(s, got, "C3 streaming vs batch", tol_max=2e-6, tol_l2=1e-6)
 
 
+_F1024 = [
+    # W,   S,  nb, nc, c0,    dyn, alpha
+    (400, 160, 80, 13, False, 0, 1.0),     # BASELINE configs[2]
+    (400, 160, 80, 13, False, 2, 1.0),     # with the delta stages (statics through the compact scratch)
+    (400, 161, 64, 12, True, 1, 1.0),      # odd shift: single-sample loads
+    (512, 256, 23, 15, True, 0, 1.0),      # the build's longest window, c0 -> 16 output columns
+    (300, 100, 40, 13, False, 2, 0.9),     # VTLN warp: the lane plan is rebuilt for the warped filterbank
+    (416, 208, 8, 4, False, 0, 1.0),       # few, long filters (one round of 136 bins)
+    (417, 139, 77, 10, False, 1, 1.1),     # 14 rows of samples (the 16-row build), odd everything
+]
+
+
+@pytest.mark.parametrize("W,S,nb,nc,c0,dyn,alpha", _F1024)
+def test_front1024_configurations(pkg, orc, W, S, nb, nc, c0, dyn, alpha):
+    """k_front1024 (1024 points, window <= 512 samples, <= 80 filters, <= 16 columns): ragged utterances at odd and even
+    offsets through the batch entry against the oracle fed each utterance alone (its 1024-tap window loses the last few
+    frames: common prefix), and the same batch through k_front_reg (MFX_NO_FRONT1024=1: a different factorisation of
+    the same transform) within the same tolerance."""
+    import os
+    rng = np.random.default_rng(W * 7 + S)
+    frames = [1, 5, 16, 17, 64, 131]
+    lens = [(T - 1) * S + W + int(rng.integers(0, S)) for T in frames]
+    offs, pos = [], 0 if (S % 2 == 0) else 1
+    for n in lens:
+        offs.append(pos)
+        pos += n + (int(rng.integers(0, 4)) if S % 2 else 2 * int(rng.integers(0, 3)))
+    pcm = np.zeros(pos, np.int16)
+    utts = [synth_utterance(n, 900 + 17 * i) for i, n in enumerate(lens)]
+    for o_, u in zip(offs, utts):
+        pcm[o_:o_ + u.size] = u
+    kw = dict(W=W, S=S, nb=nb, nc=nc, c0=c0, dyn=dyn, l1=2, l2=2, fft_size=1024)
+    m, cfg, w_o = make_pair(pkg, orc, max(lens) + 2000, **kw)
+    assert m.fft_size() == 1024 and m.dominant_kernel_name() == "k_front1024"
+    if alpha != 1.0:
+        m.set_alpha(alpha)
+    rows, total = m.batch_plan(offs, lens)
+    got = m.batch_run_host(pcm)
+    assert total == sum(frames) and got.shape[0] == total
+    os.environ["MFX_NO_FRONT1024"] = "1"
+    try:
+        m2, _, _ = make_pair(pkg, orc, max(lens) + 2000, **kw)
+    finally:
+        del os.environ["MFX_NO_FRONT1024"]
+    assert m2.dominant_kernel_name() == "k_front_reg"
+    if alpha != 1.0:
+        m2.set_alpha(alpha)
+    m2.batch_plan(offs, lens)
+    g = groups_of(dyn)
+    assert_close(got, m2.batch_run_host(pcm), "k_front1024 vs k_front_reg", groups=g)
+    D = (2 + (2 if dyn == 2 else 0)) if dyn else 0
+    checked = 0
+    for i, (T, u) in enumerate(zip(frames, utts)):
+        try:
+            want = orc.run_utterance(cfg, u, w_o, alpha=alpha, bug_compat=False)
+        except RuntimeError:   # fewer frames under the oracle's 1024-tap window than the reference accepts
+            continue
+        r0 = int(rows[i])
+        n_cmp = want.shape[0]
+        if n_cmp == 0:
+            continue
+        assert T >= n_cmp
+        if dyn and n_cmp < T:
+            n_cmp = max(0, n_cmp - D)   # the oracle's last rows replicate ITS last frame in the delta window
+        if n_cmp:
+            assert_close(got[r0:r0 + n_cmp], want[:n_cmp], "utterance %d" % i, groups=g)
+            checked += 1
+    assert checked >= 2
+
+
 def test_c5_shape_2048_odd_shift_stereo(pkg, orc):
     """BASELINE configs[4] in small: 44.1 kHz, W=1102, S=441 (odd), 2048-pt, 128 mel, 40 MFCC + d + dd,
     stereo input downmixed (L+R)>>1."""
