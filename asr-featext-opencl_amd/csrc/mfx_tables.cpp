@@ -126,17 +126,24 @@ bool build_mel_lane_plan(const MelTable &t, int num_banks, int fft_size, int max
         // from lane to lane, so a clashing filter begins up to a few pairs early (zero weights).
         bool used[16] = {false};
         int longest = 0;
+        // the round's length without any shift: a shift must not make the round longer (a two-way bank conflict costs
+        // one LDS cycle per read, a longer round a whole 8-bin trip on every lane)
+        int natural = 8;
+        for (int j = 0; j < 16; ++j) {
+            const int idx = r * 16 + j;
+            if (idx >= num_banks) continue;
+            const int m = order[idx];
+            natural = std::max(natural, (t.beg[m + 2] - (t.beg[m] & ~(align - 1)) + 7) & ~7);
+        }
         for (int j = 0; j < 16; ++j) {
             const int idx = r * 16 + j;
             if (idx >= num_banks) continue;
             const int m = order[idx];
             const int b0 = t.beg[m], b1 = t.beg[m + 2];
             int start = b0 & ~(align - 1);
-            // a few pairs early at most: a longer shift costs more in padded bins (every lane runs
-            // the round's longest span) than the two-way bank conflict it would avoid
             for (int d = 0; d < 4; ++d) {
                 const int cand = (b0 & ~(align - 1)) - align * d;
-                if (cand < 0) break;
+                if (cand < 0 || b1 - cand > natural) break;
                 if (!used[(cand / align) & 15]) {
                     start = cand;
                     break;
