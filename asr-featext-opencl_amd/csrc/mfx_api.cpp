@@ -1891,7 +1891,8 @@ extern "C" int mfx_host_mel_lane_plan(int32_t lanes, int32_t num_banks, int32_t 
     MelLanePlan p16;
     MelWavePlan p64;
     if (lanes == 16) {
-        if (!build_mel_lane_plan(t, num_banks, fft_size, max_read_bin, p16)) return MFX_ERR_CONFIG;
+        // (a 1024-point table on 16 lanes is k_front1024's plan: starts at multiples of 4 bins)
+        if (!build_mel_lane_plan(t, num_banks, fft_size, max_read_bin, p16, fft_size == 1024 ? 4 : 2)) return MFX_ERR_CONFIG;
         rounds = p16.rounds, rs = p16.row_stride, Ls = p16.L, st = &p16.start, fd = &p16.fid, ww = &p16.w;
     } else {
         if (!build_mel_wave_plan(t, num_banks, fft_size, max_read_bin, p64)) return MFX_ERR_CONFIG;

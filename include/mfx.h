@@ -189,8 +189,9 @@ int mfx_host_dct_matrix(int32_t num_banks, int32_t ceps_len, int32_t want_c0, fl
 int mfx_host_mel_item_plan(int32_t num_banks, int32_t fft_size, const float *weights, const int32_t *beg,
                            int32_t *items, int64_t items_cap, int32_t *pieces, float *w, int64_t w_cap,
                            int64_t *w_len);
-/* Lane plan of the mel walk of the fused kernels (lanes = 16: 512-point kernel, lanes = 64: long-transform kernel):
- * filters dealt to the lanes in rounds, longest first; returns the number of rounds.  Test / inspection aid. */
+/* Lane plan of the mel walk of the fused kernels (lanes = 16: 512-point kernel, and with fft_size = 1024 the short-window
+ * 1024-point kernel, whose starts are multiples of 4 bins; lanes = 64: long-transform kernel): filters dealt to the lanes
+ * in rounds, longest first; returns the number of rounds.  Test / inspection aid. */
 int mfx_host_mel_lane_plan(int32_t lanes, int32_t num_banks, int32_t fft_size, const float *weights, const int32_t *beg,
                            int32_t max_read_bin, int32_t *L, int32_t *row_stride, int32_t *start, int32_t *fid, float *w,
                            int64_t w_cap);

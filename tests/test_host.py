@@ -134,7 +134,7 @@ def test_mel_item_plan_covers_every_bin_once(pkg, nb, W2, sr, alpha):
 
 @pytest.mark.parametrize("lanes,nb,W2,sr,alpha,max_read", [
     (16, 40, 512, 16000.0, 1.0, 479), (16, 26, 512, 16000.0, 0.88, 479), (16, 15, 512, 16000.0, 1.12, 479),
-    (64, 80, 1024, 16000.0, 1.0, 1023), (64, 128, 2048, 44100.0, 1.0, 1535), (64, 23, 1024, 22050.0, 0.94, 1023),
+    (16, 80, 1024, 16000.0, 1.0, 527), (16, 64, 1024, 16000.0, 0.9, 527), (64, 80, 1024, 16000.0, 1.0, 1023), (64, 128, 2048, 44100.0, 1.0, 1535), (64, 23, 1024, 22050.0, 0.94, 1023),
     (64, 200, 2048, 44100.0, 1.0, 1535)])
 def test_mel_lane_plan_walks_every_filter_once(pkg, lanes, nb, W2, sr, alpha, max_read):
     """Lane plans of the fused kernels' mel walk (16 lanes per frame: k_front512; 64: k_front_reg): every filter sits in
@@ -158,7 +158,7 @@ def test_mel_lane_plan_walks_every_filter_once(pkg, lanes, nb, W2, sr, alpha, ma
                 continue
             assert m not in seen and 0 <= m < nb
             seen.add(m)
-            assert st % 2 == 0 and st >= 0 and st + L[r] - 1 <= max_read
+            assert st % (4 if (lanes == 16 and W2 == 1024) else 2) == 0 and st >= 0 and st + L[r] - 1 <= max_read
             want = np.zeros(L[r], np.float32)
             b0, b1 = int(beg[m]), int(beg[m + 2])
             assert st <= b0 and b1 - st <= L[r]
