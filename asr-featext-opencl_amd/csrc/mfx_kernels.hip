@@ -1175,15 +1175,20 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
             const bool live = f < n_live;
             const bool last = f0 + 4 >= n_live;
             const bool odd = !ALIGNED && ((odd0 + f * p.shift) & 1);
-            // sample pair m of this lane (n = l + 16 m) as two floats, from the raw words
-            auto pair_of = [&](int m, float &x0, float &x1) {
-                uint32_t d;
-                if (ALIGNED) {
-                    d = cur.d[m];
-                } else {
+            // Unaligned frames: the two raw words per sample pair are merged into one right away (both phases read the
+            // pairs; 2 NM raw registers held across a phase spilled 34 of them) and the next frames are requested here.
+            uint32_t dd[ALIGNED ? 1 : NM];
+            if (!ALIGNED) {
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
                     const uint32_t d0 = cur.d[2 * m], d1 = cur.d[2 * m + 1];
-                    d = odd ? ((d0 >> 16) | (d1 << 16)) : d0;
+                    dd[m] = odd ? __builtin_amdgcn_alignbit(d1, d0, 16) : d0;
                 }
+                pcm_issue<ALIGNED, NM>(cur, last ? cnxt.rsrc : ccur.rsrc, last ? lane_off(cnxt, slot) : lane_off(ccur, f + 4));
+            }
+            // sample pair m of this lane (n = l + 16 m) as two floats
+            auto pair_of = [&](int m, float &x0, float &x1) {
+                const uint32_t d = ALIGNED ? cur.d[m] : dd[m];
                 x0 = (float)(int)(short)(d & 0xffffu);
                 x1 = (float)((int)d >> 16);
             };
@@ -1269,7 +1274,7 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
                     }
                 }
                 // the raw words are consumed: prefetch the next 4 frames (of this chunk, or the first of the next chunk)
-                pcm_issue<ALIGNED, NM>(cur, last ? cnxt.rsrc : ccur.rsrc, last ? lane_off(cnxt, slot) : lane_off(ccur, f + 4));
+                if (ALIGNED) pcm_issue<ALIGNED, NM>(cur, last ? cnxt.rsrc : ccur.rsrc, last ? lane_off(cnxt, slot) : lane_off(ccur, f + 4));
                 fft256(a);
                 const float m128r = a[8].x + a[8].x, m128i = a[8].y + a[8].y;
                 magE128 = __builtin_amdgcn_sqrtf(m128r * m128r + m128i * m128i);
