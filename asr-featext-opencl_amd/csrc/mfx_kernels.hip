@@ -2090,25 +2090,27 @@ __global__ void __launch_bounds__(256) k_melcep(MelcepParams p)
 // ------------------------------------------------------------------------------------------------
 // FAST16: cols <= 16 -> a row is 16 consecutive work items (no integer division by a run-time
 // column count, 13..16 consecutive floats per row piece); otherwise the generic index split.
-template <bool FAST16>
+template <bool FAST16, int ROWS>
 __global__ void __launch_bounds__(256) k_delta(DeltaParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Segment sg = p.inline_seg ? p.seg0 : p.segs[blockIdx.y];
-    const int r0 = blockIdx.x * kDeltaRows;
+    const int r0 = blockIdx.x * ROWS;
     if (r0 >= sg.n_out) return;
-    const int rows = min(kDeltaRows, sg.n_out - r0);
+    const int rows = min(ROWS, sg.n_out - r0);
     const int cols = p.cols, l1 = p.l1, l2 = p.l2, D = l1 + l2;
     const int cw = FAST16 ? 16 : cols; // row width in work items and in LDS
     const int tid = threadIdx.x;
     float *s_pad = smem;                             // [rows + 2D][cw]
-    float *s_d = smem + (kDeltaRows + 2 * D) * cw;   // [rows + 2*l2][cw]
+    float *s_d = smem + (ROWS + 2 * D) * cw;   // [rows + 2*l2][cw]
+    // (tile indices stay below 2^16: floor(i / cols) as a multiply-high instead of an integer division per element)
+    const uint32_t magic_c = 0xffffffffu / (uint32_t)(cols > 0 ? cols : 1) + 1;
     auto split = [&](int i, int &rr, int &c) {
         if (FAST16) {
             rr = i >> 4;
             c = i & 15;
         } else {
-            rr = i / cols;
+            rr = (int)__umulhi((uint32_t)i, magic_c);
             c = i - rr * cols;
         }
     };
@@ -2135,7 +2137,7 @@ __global__ void __launch_bounds__(256) k_delta(DeltaParams p)
         }
         __syncthreads();
     }
-    float *s_dd = s_d + (kDeltaRows + 2 * l2) * cw;  // [rows][cw]
+    float *s_dd = s_d + (ROWS + 2 * l2) * cw;  // [rows][cw]
     if (l2 > 0) {
         float den2 = 0.f;
         for (int l = 1; l <= l2; ++l) den2 += (float)(l * l);
@@ -2650,9 +2652,16 @@ hipError_t launch_delta(const DeltaParams &p, hipStream_t stream)
     }
     const bool fast16 = p.cols <= 16;
     const int cw = fast16 ? 16 : p.cols;
-    const size_t lds = (size_t)((kDeltaRows + 2 * D) + (kDeltaRows + 2 * p.l2) + kDeltaRows) * cw * sizeof(float);
+    // wide rows: tiles of MFX_DELTA_WIDE_ROWS output rows (less LDS per block: more blocks per CU in flight)
+#ifndef MFX_DELTA_WIDE_ROWS
+#define MFX_DELTA_WIDE_ROWS 32   // (C5: k_delta 0.072 -> 0.055 ms; 16 rows: 0.063)
+#endif
+    constexpr int RW = MFX_DELTA_WIDE_ROWS;
+    const int rows_t = fast16 ? kDeltaRows : RW;
+    const int tiles_x = p.tiles_per_seg_max * (kDeltaRows / rows_t);
+    const size_t lds = (size_t)((rows_t + 2 * D) + (rows_t + 2 * p.l2) + rows_t) * cw * sizeof(float);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fast16 ? (const void *)k_delta<true> : (const void *)k_delta<false>,
+        hipError_t e = hipFuncSetAttribute(fast16 ? (const void *)k_delta<true, kDeltaRows> : (const void *)k_delta<false, RW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
@@ -2662,9 +2671,9 @@ hipError_t launch_delta(const DeltaParams &p, hipStream_t stream)
         q.segs = p.segs + s0;
         q.n_segs = (p.n_segs - s0) < 65535 ? (p.n_segs - s0) : 65535;
         if (fast16)
-            hipLaunchKernelGGL(k_delta<true>, dim3(p.tiles_per_seg_max, q.n_segs), dim3(256), lds, stream, q);
+            hipLaunchKernelGGL((k_delta<true, kDeltaRows>), dim3(tiles_x, q.n_segs), dim3(256), lds, stream, q);
         else
-            hipLaunchKernelGGL(k_delta<false>, dim3(p.tiles_per_seg_max, q.n_segs), dim3(256), lds, stream, q);
+            hipLaunchKernelGGL((k_delta<false, RW>), dim3(tiles_x, q.n_segs), dim3(256), lds, stream, q);
     }
     return hipGetLastError();
 }
