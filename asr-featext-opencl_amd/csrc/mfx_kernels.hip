@@ -1939,7 +1939,24 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
                         const int L = p.mel64_L[r];
                         const float *mg = mag + st;
                         float acc = 0.f;
-                        for (int s2 = 0; s2 < L; s2 += 8) {
+                        int s2 = 0;
+                        if (LOG2M == 10) // (2048 points: 12 reads in flight per trip, half the dependent round trips: C5 -1 %)
+                            for (; s2 + 16 <= L; s2 += 16) {
+                                float4 w[4];
+                                float2 mm[8];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) w[q] = lds_read_b128((const float4 *)(wrow + s2 + 4 * q));
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) mm[q] = lds_read_b64((const float2 *)(mg + s2 + 2 * q));
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    acc += w[q].x * mm[2 * q].x;
+                                    acc += w[q].y * mm[2 * q].y;
+                                    acc += w[q].z * mm[2 * q + 1].x;
+                                    acc += w[q].w * mm[2 * q + 1].y;
+                                }
+                            }
+                        for (; s2 < L; s2 += 8) {
                             const float4 w0 = lds_read_b128((const float4 *)(wrow + s2));
                             const float4 w1 = lds_read_b128((const float4 *)(wrow + s2 + 4));
                             float2 mm[4];
