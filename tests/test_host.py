@@ -393,3 +393,34 @@ def test_sanitizer_targets_run_clean():
         r = subprocess.run(["make", "-C", d, "asan"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-3000:]
         assert tag in r.stdout and "clean" in r.stdout and "ERROR" not in r.stdout
+
+
+def test_front1024_decimation_identity():
+    """The factorisation k_front1024 computes (csrc/mfx_kernels.hip), restated in numpy in double precision: for a real
+    frame that is zero from sample 512 on, the 1024-point DFT is two 256-point complex DFTs of the packed samples
+    z[m] = x[2m] + i x[2m+1] -- even bins through the usual real split of FFT256(z), odd bins through the same split
+    arithmetic applied to V = FFT256(z W_512^m) with partner bin 255 - k and twiddle -i W_1024^(2k+1); the paired form
+    X[bin(k)] = (S + T) / 2, X[bin(partner)] = conj(S - T) / 2 is what the kernel evaluates per lane."""
+    rng = np.random.default_rng(5)
+    for W in (400, 512, 37):
+        x = np.zeros(1024)
+        x[:W] = rng.standard_normal(W) * 1000.0
+        X = np.fft.fft(x)                      # forward DFT, e^{-2 pi i n k / N}: the reference's convention
+        z = x[0:512:2] + 1j * x[1:512:2]
+        m = np.arange(256)
+        Z = np.fft.fft(z)
+        V = np.fft.fft(z * np.exp(-2j * np.pi * m / 512))
+        k = np.arange(128)
+        # phase E: partner 256 - k (bin 0 pairs with itself and yields the Nyquist bin), twiddle -i W_512^k
+        pe = (256 - k) % 256
+        S, D = Z[k] + np.conj(Z[pe]), Z[k] - np.conj(Z[pe])
+        T = (-1j * np.exp(-2j * np.pi * k / 512)) * D
+        assert np.allclose((S + T) / 2, X[2 * k], rtol=0, atol=1e-6 * np.abs(X).max())
+        assert np.allclose(np.conj(S - T) / 2, X[2 * (256 - k)], rtol=0, atol=1e-6 * np.abs(X).max())
+        assert np.allclose(2 * Z[128].conj() / 2, X[256], rtol=0, atol=1e-6 * np.abs(X).max())   # the self-paired bin
+        # phase O: partner 255 - k, twiddle -i W_1024^(2k+1), no self-paired bins
+        po = 255 - k
+        S, D = V[k] + np.conj(V[po]), V[k] - np.conj(V[po])
+        T = (-1j * np.exp(-2j * np.pi * (2 * k + 1) / 1024)) * D
+        assert np.allclose((S + T) / 2, X[2 * k + 1], rtol=0, atol=1e-6 * np.abs(X).max())
+        assert np.allclose(np.conj(S - T) / 2, X[2 * po + 1], rtol=0, atol=1e-6 * np.abs(X).max())
