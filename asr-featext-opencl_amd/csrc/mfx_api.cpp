@@ -725,7 +725,7 @@ extern "C" int mfx_profile_read(mfx_handle *h, int32_t *launches, double *kernel
 extern "C" const char *mfx_dominant_kernel_name(const mfx_handle *h)
 {
     if (!h) return "";
-    return h->fast512 ? "k_front512" : (h->fast1024 && h->fused_ok) ? "k_front1024" : h->W2 >= 1024 ? "k_front_reg" : "k_front_wave"; // names as rocprofv3 prints them
+    return h->fast512 ? "k_front512" : (h->fast1024 && h->fused_ok && (h->W <= 512 || h->batch_aligned)) ? "k_front1024" : h->W2 >= 1024 ? "k_front_reg" : "k_front_wave"; // names as rocprofv3 prints them
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -741,7 +741,28 @@ extern "C" int mfx_set_window(mfx_handle *h, const float *window)
     std::memcpy(padded.data(), window, sizeof(float) * h->W);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, upload(h->d_window, padded));
-    if (h->fast1024) {
+    if (h->fast1024 && h->W > 512) {
+        // k_front1024, window longer than 512 samples: the taps of all 32 rows of sample pairs (with the output scale
+        // folded in) and the twiddles W_512^n of the first 16 rows; the kernel folds the frame's halves itself
+        const float fold = 0.5f / (float)h->W2;
+        std::vector<float> tw512;
+        build_twiddles(512, 256, tw512);
+        std::vector<float> taps(16 * 32 * 2, 0.f), tw(16 * 16 * 2, 0.f);
+        for (int l = 0; l < 16; ++l) {
+            for (int m = 0; m < 32; ++m) {
+                const int n = l + 16 * m;
+                taps[2 * (l * 32 + m)] = padded[2 * n] * fold;
+                taps[2 * (l * 32 + m) + 1] = padded[2 * n + 1] * fold;
+            }
+            for (int m = 0; m < 16; ++m) {
+                const int n = l + 16 * m;
+                tw[2 * (l * 16 + m)] = tw512[2 * n];
+                tw[2 * (l * 16 + m) + 1] = tw512[2 * n + 1];
+            }
+        }
+        HIP_TRY(h, upload(h->d_win1024o, taps));
+        HIP_TRY(h, upload(h->d_winpair, tw));
+    } else if (h->fast1024) {
         // phase O of k_front1024: (taps of pair n) x W_512^n as the real 2 x 2 form
         //   re = A x0 + B x1,  im = C x0 + D x1,   (A, B, C, D) = (t0 c, -t1 s, t0 s, t1 c),  W_512^n = c + i s
         // with the same output scale folded in (exact: a power of two)
@@ -762,7 +783,7 @@ extern "C" int mfx_set_window(mfx_handle *h, const float *window)
             }
         HIP_TRY(h, upload(h->d_win1024o, wo));
     }
-    if (h->fast512 || h->fast1024) {
+    if (h->fast512 || (h->fast1024 && h->W <= 512)) {
         // The 512-point kernel's copy carries the output scale 0.5 / W2 (1/2 of the real split, 1/W2 of
         // mfcccpu.cpp:203).  It is a power of two, so scaling the taps instead of the magnitudes changes no
         // bit of the result (every intermediate is the same value times 2^-10) and saves a multiply per bin.
@@ -1536,7 +1557,7 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
     // Which front end: the 512-point register kernel, else the fused wave-per-frame kernel when its
     // LDS fits, else spectrum through an HBM slab + melcep.
     const bool fused512 = h->fast512 && h->fused_ok;
-    const bool fused1024 = h->fast1024 && h->fused_ok;
+    const bool fused1024 = h->fast1024 && h->fused_ok && (h->W <= 512 || h->batch_aligned); // (long windows: aligned frames only)
     // (up to 2048 points the fused form saves the spectrum's round trip through HBM -- 8 KB per frame at 2048
     // points; at 4096 points the tables + per-wave buffers no longer leave enough waves per CU)
     const bool fusedgen = !fused512 && !fused1024 && h->W2 <= 2048 && (h->W2 < 1024 || h->wplan_ok) &&

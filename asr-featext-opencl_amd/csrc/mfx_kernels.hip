@@ -1219,13 +1219,36 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
                 fft16(a);
             };
 
+            // NM > 16 (a window longer than 512 samples, aligned frames only): the second half of the frame folds onto the
+            // first before the two transforms,  Y0[m] = z[m] + z[m + 256]  (even bins),  Y1[m] = (z[m] - z[m + 256]) W_512^m
+            // (odd bins).  The tables change roles: s_winO holds the window taps of all 32 rows of sample pairs, s_win the
+            // twiddles W_512^(l + 16 m).
+            constexpr bool FULL = NM > 16;
+            static_assert(!FULL || ALIGNED, "windows longer than 512 samples: aligned frames only");
+            // products (tap x sample) of the frame's two halves for row m, folded: sum (phase E) or difference (phase O).
+            // `fresh` re-reads the raw words opaquely, so that phase E converts them again instead of keeping 64 floats alive.
+            auto folded = [&](int m, bool want_sum, bool fresh) -> float2 {
+                uint32_t dA = cur.d[m], dB = (m + 16 < NM) ? cur.d[(m + 16 < NM) ? m + 16 : 0] : 0u;
+                if (fresh) asm volatile("" : "+v"(dA), "+v"(dB));
+                const float2 tA = ((const float2 *)(s_winO + l * kTabStrideO))[m];
+                float2 r = make_float2(tA.x * (float)(int)(short)(dA & 0xffffu), tA.y * (float)((int)dA >> 16));
+                if (m + 16 < NM) {
+                    const float2 tB = ((const float2 *)(s_winO + l * kTabStrideO))[m + 16];
+                    const float2 pB = make_float2(tB.x * (float)(int)(short)(dB & 0xffffu), tB.y * (float)((int)dB >> 16));
+                    r = want_sum ? make_float2(r.x + pB.x, r.y + pB.y) : make_float2(r.x - pB.x, r.y - pB.y);
+                }
+                return r;
+            };
+
             // ---- phase O: odd bins
             float magO_k[8], magO_p[8];
             {
                 float2 a[16];
 #pragma unroll
                 for (int m = 0; m < 16; ++m) {
-                    if (m < NM) {
+                    if (FULL) {
+                        a[m] = cmul(folded(m, false, false), ((const float2 *)(s_win + l * kTabStride))[m]); // x W_512^(l + 16 m)
+                    } else if (m < NM) {
                         float x0, x1;
                         pair_of(m, x0, x1);
                         const float4 t = ((const float4 *)(s_winO + l * kTabStrideO))[m];
@@ -1259,12 +1282,17 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
             float magE_k[8], magE_p[8], magE128;
             {
                 float2 a[16];
-                float4 wq[(NM + 1) / 2];
+                constexpr int NW = FULL ? 1 : (NM + 1) / 2;
+                float4 wq[NW];
+                if (!FULL) {
 #pragma unroll
-                for (int m = 0; m < (NM + 1) / 2; ++m) wq[m] = ((const float4 *)(s_win + l * kTabStride))[m];
+                    for (int m = 0; m < NW; ++m) wq[m] = ((const float4 *)(s_win + l * kTabStride))[m];
+                }
 #pragma unroll
                 for (int m = 0; m < 16; ++m) {
-                    if (m < NM) {
+                    if (FULL) {
+                        a[m] = folded(m, true, true);
+                    } else if (m < NM) {
                         float x0, x1;
                         pair_of(m, x0, x1);
                         const float2 w = (m & 1) ? make_float2(wq[m >> 1].z, wq[m >> 1].w) : make_float2(wq[m >> 1].x, wq[m >> 1].y);
@@ -2436,9 +2464,10 @@ size_t front1024_lds_bytes(const FrontParams &p)
     return f * sizeof(float);
 }
 
+// (windows longer than 512 samples run on aligned frames only: launch_front1024 refuses the others)
 bool front1024_supported(int fft_size, int window_size, int num_banks, int cols, int channels, int ceps_len)
 {
-    return fft_size == 1024 && window_size > 0 && window_size <= 512 && channels <= 1 && num_banks >= 1 &&
+    return fft_size == 1024 && window_size > 0 && window_size <= 1024 && channels <= 1 && num_banks >= 1 &&
            num_banks <= 4 * kDctStepsL && cols <= 16 && ceps_len > 0;
 }
 
@@ -2462,6 +2491,10 @@ hipError_t launch1024(const FrontParams &p, hipStream_t stream)
 hipError_t launch_front1024(const FrontParams &p, bool aligned, int nm16, hipStream_t stream)
 {
     if (p.n_chunks <= 0) return hipSuccess;
+    if (nm16 > 16) { // NM = rows of 16 sample pairs that carry window taps: 24 covers W <= 768, 32 the full 1024
+        if (!aligned) return hipErrorInvalidValue;
+        return nm16 <= 24 ? launch1024<true, 24>(p, stream) : launch1024<true, 32>(p, stream);
+    }
     const bool nm13 = nm16 <= 13;
     if (aligned) return nm13 ? launch1024<true, 13>(p, stream) : launch1024<true, 16>(p, stream);
     return nm13 ? launch1024<false, 13>(p, stream) : launch1024<false, 16>(p, stream);

@@ -440,12 +440,16 @@ _F1024 = [
     (300, 100, 40, 13, False, 2, 0.9),     # VTLN warp: the lane plan is rebuilt for the warped filterbank
     (416, 208, 8, 4, False, 0, 1.0),       # few, long filters (one round of 136 bins)
     (417, 139, 77, 10, False, 1, 1.1),     # 14 rows of samples (the 16-row build), odd everything
+    (800, 320, 64, 13, False, 2, 1.0),     # window longer than 512 samples: the frame's halves are folded (24-row build)
+    (1024, 256, 80, 13, False, 0, 1.0),    # full-length window (32-row build)
+    (600, 200, 40, 12, True, 1, 0.9),
+    (1000, 333, 48, 13, False, 1, 1.0),    # long window on unaligned frames: stays on k_front_reg
 ]
 
 
 @pytest.mark.parametrize("W,S,nb,nc,c0,dyn,alpha", _F1024)
 def test_front1024_configurations(pkg, orc, W, S, nb, nc, c0, dyn, alpha):
-    """k_front1024 (1024 points, window <= 512 samples, <= 80 filters, <= 16 columns): ragged utterances at odd and even
+    """k_front1024 (1024 points, <= 80 filters, <= 16 columns; windows longer than 512 samples on aligned frames only): ragged utterances at odd and even
     offsets through the batch entry against the oracle fed each utterance alone (its 1024-tap window loses the last few
     frames: common prefix), and the same batch through k_front_reg (MFX_NO_FRONT1024=1: a different factorisation of
     the same transform) within the same tolerance."""
@@ -453,6 +457,8 @@ def test_front1024_configurations(pkg, orc, W, S, nb, nc, c0, dyn, alpha):
     rng = np.random.default_rng(W * 7 + S)
     frames = [1, 5, 16, 17, 64, 131]
     lens = [(T - 1) * S + W + int(rng.integers(0, S)) for T in frames]
+    if W > 512 and S % 2 == 0:
+        lens = [n + (n & 1) for n in lens]     # long windows: every utterance at an even offset (aligned frames)
     offs, pos = [], 0 if (S % 2 == 0) else 1
     for n in lens:
         offs.append(pos)
@@ -463,10 +469,11 @@ def test_front1024_configurations(pkg, orc, W, S, nb, nc, c0, dyn, alpha):
         pcm[o_:o_ + u.size] = u
     kw = dict(W=W, S=S, nb=nb, nc=nc, c0=c0, dyn=dyn, l1=2, l2=2, fft_size=1024)
     m, cfg, w_o = make_pair(pkg, orc, max(lens) + 2000, **kw)
-    assert m.fft_size() == 1024 and m.dominant_kernel_name() == "k_front1024"
+    assert m.fft_size() == 1024
     if alpha != 1.0:
         m.set_alpha(alpha)
     rows, total = m.batch_plan(offs, lens)
+    assert m.dominant_kernel_name() == ("k_front1024" if (W <= 512 or S % 2 == 0) else "k_front_reg")
     got = m.batch_run_host(pcm)
     assert total == sum(frames) and got.shape[0] == total
     os.environ["MFX_NO_FRONT1024"] = "1"

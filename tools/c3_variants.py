@@ -11,7 +11,7 @@ dev = torch.device("cuda", 0)
 n = 57_600_000
 pcm = (3000.0 * torch.randn((n,), device=dev)).round().clamp(-32768, 32767).to(torch.int16)
 for name, W, S, off in (("shift 160, even offset", 400, 160, 0), ("shift 161 (odd)", 400, 161, 0), ("shift 160, odd offset", 400, 160, 1),
-                        ("512 taps, shift 160", 512, 160, 0)):
+                        ("512 taps, shift 160", 512, 160, 0), ("768 taps, shift 160", 768, 160, 0), ("1024 taps, shift 160", 1024, 160, 0)):
     for no in ("0", "1"):
         os.environ["MFX_NO_FRONT1024"] = no
         m = pkg.MfccHip(n + 1000, W, S, 80, 16000.0, 64.0, 8000.0, 13, False, 22.0, 0, 0, 3, 3, True, fft_size=1024)
