@@ -11,8 +11,10 @@ worst = 0.0
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 routed = 0
 for case in range(n_cases):
-    W = int(rng.integers(40, 513))
+    W = int(rng.integers(40, 1025))
     S = int(rng.integers(max(8, W // 6), W + 1))
+    if W > 512:
+        S += S & 1   # long windows run on k_front1024 for aligned frames only
     nb = int(rng.integers(6, 81))
     c0 = bool(rng.integers(0, 2))
     nc = int(rng.integers(2, min(nb, 15 if c0 else 16) + 1))
@@ -21,10 +23,13 @@ for case in range(n_cases):
     alpha = float(rng.choice([1.0, 1.0, 0.88, 1.12]))
     frames = [int(x) for x in rng.integers(1, 90, size=int(rng.integers(1, 9)))]
     lens = [(T - 1) * S + W + int(rng.integers(0, S)) for T in frames]
-    offs, pos = [], int(rng.integers(0, 3))
+    even = W > 512
+    if even:
+        lens = [n + (n & 1) for n in lens]
+    offs, pos = [], 0 if even else int(rng.integers(0, 3))
     for n in lens:
         offs.append(pos)
-        pos += n + int(rng.integers(0, 5))
+        pos += n + (2 * int(rng.integers(0, 3)) if even else int(rng.integers(0, 5)))
     pcm = (4000.0 * rng.standard_normal(pos)).round().clip(-32768, 32767).astype(np.int16)
     outs = []
     for no in ("0", "1"):
