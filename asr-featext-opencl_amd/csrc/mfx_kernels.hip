@@ -574,9 +574,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
     float *s_tw = s_win + 16 * kTabStride;           // [16 l][kTabStride]: W_256^(l k), k = 0..15
     float *s_split = s_tw + 16 * kTabStride;         // [16 l][kSplitStride]: -i W_512^(l + 16 p), p = 0..7
     float *s_melw = s_split + 16 * kSplitStride;     // [16][RS]
-    int *s_mstart = (int *)(s_melw + 16 * RS);       // [rounds][16]
-    int *s_mfid = s_mstart + 16 * rounds;            // [rounds][16]
-    float *s_dct = (float *)(s_mfid + 16 * rounds);  // [cols][DS]
+    int *s_mmeta = (int *)(s_melw + 16 * RS);        // [rounds][16] (first bin, filter id): one 8-byte read per round
+    float *s_dct = (float *)(s_mmeta + 32 * rounds); // [cols][DS]
     // dct_mode 0: transposed matrix [cols][DS]; dct_mode 1: matrix-pipe B operands per lane, [64][kDctRow]
     const int dct_floats = !p.dct ? 0 : p.dct_mode == 1 ? 64 * kDctRow : cols * DS;
     float *s_wave = s_dct + dct_floats + wave * (4 * kSlot);
@@ -600,8 +599,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
     if (!TO_SPEC) {
         for (int i = tid; i < 16 * RS; i += kThreads) s_melw[i] = p.mel_lane_w[i];
         for (int i = tid; i < 16 * rounds; i += kThreads) {
-            s_mstart[i] = p.mel_lane_start[i];
-            s_mfid[i] = p.mel_lane_fid[i];
+            s_mmeta[2 * i] = p.mel_lane_start[i];
+            s_mmeta[2 * i + 1] = p.mel_lane_fid[i];
         }
         if (p.dct_mode == 1) {
             // B operand of K step j on lane (k = lane >> 4, n = lane & 15) is dct[4 j + k][n]; zeros beyond the matrix
@@ -934,10 +933,13 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
                     // copies: all 64 lanes read valid energies), so register 0 of the result is out[slot][c] on
                     // lane (slot, c) -- exactly the lane that stores it.
                     float *lm = xb + kMelOff + 8 * slot;
+                    const int2 *mmeta = (const int2 *)s_mmeta + l;
                     for (int r = 0; r < rounds; ++r) {
                         const int L = p.mel_L[r];
-                        const float *mg = mg0 + s_mstart[r * 16 + l];
-                        const int fid = s_mfid[r * 16 + l];
+                        const int2 mt = *mmeta;
+                        mmeta += 16;
+                        const float *mg = mg0 + mt.x;
+                        const int fid = mt.y;
                         float acc = 0.f;
                         for (int s = 0; s < L; s += 8) {
                             float4 w[2];
@@ -975,10 +977,13 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
                     if (live && (l < cols || p.feat_pitch == 16)) dst[l] = outv;
                 } else {
                     float *melbuf = xb + kMelOff;
+                    const int2 *mmeta = (const int2 *)s_mmeta + l;
                     for (int r = 0; r < rounds; ++r) {
                         const int L = p.mel_L[r];
-                        const float *mg = mg0 + s_mstart[r * 16 + l];
-                        const int fid = s_mfid[r * 16 + l];
+                        const int2 mt = *mmeta;
+                        mmeta += 16;
+                        const float *mg = mg0 + mt.x;
+                        const int fid = mt.y;
                         float acc = 0.f;
                         for (int s = 0; s < L; s += 4) {
                             const float4 w = *(const float4 *)(wrow + s);
@@ -1089,9 +1094,8 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
     float *s_splitE = s_tw + 16 * kTabStride;          // [16 l][kSplitStride]: -i W_1024^(2 (l + 16 p))
     float *s_splitO = s_splitE + 16 * kSplitStride;    // [16 l][kSplitStride]: -i W_1024^(2 (l + 16 p) + 1)
     float *s_melw = s_splitO + 16 * kSplitStride;      // [16][RS]
-    int *s_mstart = (int *)(s_melw + 16 * RS);         // [rounds][16]
-    int *s_mfid = s_mstart + 16 * rounds;              // [rounds][16]
-    float *s_dct = (float *)(s_mfid + 16 * rounds);    // [64][kDctRowL]: matrix-pipe B operands per lane
+    int *s_mmeta = (int *)(s_melw + 16 * RS);          // [rounds][16] (first bin, filter id): one 8-byte read per round
+    float *s_dct = (float *)(s_mmeta + 32 * rounds);   // [64][kDctRowL]: matrix-pipe B operands per lane
     float *s_wave = s_dct + 64 * kDctRowL + wave * (4 * kSlotL);
     float *xb = s_wave + slot * kSlotL;
     int *s_ctr = (int *)(s_dct + 64 * kDctRowL + kWavesL * (4 * kSlotL));
@@ -1108,8 +1112,8 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
     }
     for (int i = tid; i < 16 * RS; i += kWavesL * 64) s_melw[i] = p.mel_lane_w[i];
     for (int i = tid; i < 16 * rounds; i += kWavesL * 64) {
-        s_mstart[i] = p.mel_lane_start[i];
-        s_mfid[i] = p.mel_lane_fid[i];
+        s_mmeta[2 * i] = p.mel_lane_start[i];
+        s_mmeta[2 * i + 1] = p.mel_lane_fid[i];
     }
     for (int i = tid; i < 64 * kDctRowL; i += kWavesL * 64) {
         const int ln = i / kDctRowL, j = i - ln * kDctRowL, m = 4 * j + (ln >> 4), n = ln & 15;
@@ -1346,11 +1350,14 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
             const float *wrow = s_melw + l * RS;
             float *dst = p.feat + (out_row + f0) * (int64_t)p.feat_pitch + slot * p.feat_pitch;
             float *lm = xb + kMelOffL + 8 * slot;
+            const int2 *mmeta = (const int2 *)s_mmeta + l;
             for (int r = 0; r < rounds; ++r) {
                 const int L = p.mel_L[r];
-                const int st = s_mstart[r * 16 + l] >> 1;
+                const int2 mt = *mmeta;
+                mmeta += 16;
+                const int st = mt.x >> 1;
                 const float *me = xb + st, *mo = xb + kOddOffL + st;
-                const int fid = s_mfid[r * 16 + l];
+                const int fid = mt.y;
                 float acc = 0.f;
                 for (int s = 0; s < L; s += 8) {
                     float4 w[2];
