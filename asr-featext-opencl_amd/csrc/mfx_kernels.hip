@@ -600,7 +600,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
         for (int i = tid; i < 16 * RS; i += kThreads) s_melw[i] = p.mel_lane_w[i];
         for (int i = tid; i < 16 * rounds; i += kThreads) {
             s_mmeta[2 * i] = p.mel_lane_start[i];
-            s_mmeta[2 * i + 1] = p.mel_lane_fid[i];
+            const int fid = p.mel_lane_fid[i];
+            s_mmeta[2 * i + 1] = (fid < 0 && p.dct_mode == 1) ? 4 * kDctSteps : fid; // (matrix-pipe form: idle lanes park their value in a word nobody reads)
         }
         if (p.dct_mode == 1) {
             // B operand of K step j on lane (k = lane >> 4, n = lane & 15) is dct[4 j + k][n]; zeros beyond the matrix
@@ -957,7 +958,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
                             }
                         }
                         wrow += L;
-                        lm[fid >= 0 ? fid : 4 * kDctSteps] = MFX_LOG(fmaxf(acc, 1e-30f)); // idle lane: a word nobody reads
+                        lm[fid] = MFX_LOG(fmaxf(acc, 1e-30f)); // (idle lanes: fid names a word nobody reads)
                     }
                     wave_sync();
                     const float *arow = s_wave + (l >> 2) * (kSlot + 8) + kMelOff + slot; // A[row l][k = slot] of K step 0
@@ -1112,8 +1113,9 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
     }
     for (int i = tid; i < 16 * RS; i += kWavesL * 64) s_melw[i] = p.mel_lane_w[i];
     for (int i = tid; i < 16 * rounds; i += kWavesL * 64) {
-        s_mmeta[2 * i] = p.mel_lane_start[i];
-        s_mmeta[2 * i + 1] = p.mel_lane_fid[i];
+        s_mmeta[2 * i] = p.mel_lane_start[i] >> 1; // (index into the even / odd magnitude arrays)
+        const int fid = p.mel_lane_fid[i];
+        s_mmeta[2 * i + 1] = fid < 0 ? 4 * kDctStepsL : fid; // idle lanes park their value in a word nobody reads
     }
     for (int i = tid; i < 64 * kDctRowL; i += kWavesL * 64) {
         const int ln = i / kDctRowL, j = i - ln * kDctRowL, m = 4 * j + (ln >> 4), n = ln & 15;
@@ -1355,8 +1357,7 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
                 const int L = p.mel_L[r];
                 const int2 mt = *mmeta;
                 mmeta += 16;
-                const int st = mt.x >> 1;
-                const float *me = xb + st, *mo = xb + kOddOffL + st;
+                const float *me = xb + mt.x, *mo = xb + kOddOffL + mt.x;
                 const int fid = mt.y;
                 float acc = 0.f;
                 for (int s = 0; s < L; s += 8) {
@@ -1378,7 +1379,7 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
                     }
                 }
                 wrow += L;
-                lm[fid >= 0 ? fid : 4 * kDctStepsL] = MFX_LOG(fmaxf(acc, 1e-30f)); // idle lane: a word nobody reads
+                lm[fid] = MFX_LOG(fmaxf(acc, 1e-30f)); // (idle lanes: fid names a word nobody reads)
             }
             wave_sync();
             // ---- DCT-II + lifter on the matrix pipe (see k_front512): frame `slot` in rows 4 slot .. 4 slot + 3
