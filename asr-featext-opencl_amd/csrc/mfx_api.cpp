@@ -869,12 +869,6 @@ int download_rows(mfx_handle *h, float *dst, const float *d_src, size_t count)
     }
     if (h->h_out_stage_n < count) {
         if (h->h_out_stage) (void)hipHostFree(h->h_out_stage);
-    if (h->stream_up) (void)hipStreamDestroy(h->stream_up);
-    if (h->stream_dn) (void)hipStreamDestroy(h->stream_dn);
-    for (int i = 0; i < 16; ++i) {
-        if (h->ev_up[i]) (void)hipEventDestroy(h->ev_up[i]);
-        if (h->ev_run[i]) (void)hipEventDestroy(h->ev_run[i]);
-    }
         h->h_out_stage = nullptr;
         h->h_out_stage_n = 0;
         const size_t want = std::max(count, (size_t)h->cap_rows * h->width);
@@ -952,6 +946,16 @@ extern "C" int mfx_set_input(mfx_handle *h, const int16_t *pcm, int32_t samples,
     // previous contents the stream has long consumed (get_output_data / mfx_synchronize waited for it)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     bool direct = false;
+    // `pcm` must be free for the caller on EVERY return: when the block is DMA'd straight from the caller's pinned buffer
+    // (upload_block sets `direct`), any exit -- the error returns below included -- first waits for that copy
+    struct DirectWait {
+        mfx_handle *h;
+        const bool *direct;
+        ~DirectWait()
+        {
+            if (*direct && h->ev_copy[0]) (void)hipEventSynchronize(h->ev_copy[0]);
+        }
+    } direct_wait{h, &direct};
 
     h->last_calc_flushed = h->flushed;
     int window_count = 0, wcnd = 0;
@@ -1762,27 +1766,41 @@ extern "C" int mfx_batch_run_host(mfx_handle *h, const int16_t *pcm, int64_t pcm
             }
         }
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+        // every utterance inside the caller's array BEFORE the first copy is queued (batch_run_range only looks at the
+        // slice it is given, and only after that slice's upload is in flight)
+        for (int u = 0; u < h->n_utt; ++u)
+            if (h->utt_off[u] < 0 || h->utt_off[u] + h->utt_len[u] > pcm_samples_total)
+                return fail(h, MFX_ERR_ARG, "utterance outside the PCM array");
         const int ch = h->channels;
-        for (int k = 0; k < K; ++k) {
+        // one slice; an error leaves copies in flight on three streams, which slices_done drains before returning
+        auto run_slice = [&](int k) -> int {
             const int u0 = (int)((int64_t)h->n_utt * k / K), u1 = (int)((int64_t)h->n_utt * (k + 1) / K);
             // samples [s0, s1) of the array hold the slice (s0 rounded down to an even sample: 4-byte aligned pieces)
             const int64_t s0 = (k == 0 ? 0 : h->utt_off[u0]) & ~(int64_t)1;
-            const int64_t s1 = k + 1 == K ? pcm_samples_total : h->utt_off[u1];
-            HIP_TRY(h, hipMemcpyAsync(h->d_host_pcm.p + s0 * ch, pcm + s0 * ch, (size_t)(s1 - s0) * ch * sizeof(int16_t),
-                                      hipMemcpyHostToDevice, h->stream_up));
+            const int64_t s1 = std::min<int64_t>(k + 1 == K ? pcm_samples_total : h->utt_off[u1], pcm_samples_total);
+            if (s1 > s0)
+                HIP_TRY(h, hipMemcpyAsync(h->d_host_pcm.p + s0 * ch, pcm + s0 * ch, (size_t)(s1 - s0) * ch * sizeof(int16_t),
+                                          hipMemcpyHostToDevice, h->stream_up));
             HIP_TRY(h, hipEventRecord(h->ev_up[k], h->stream_up));
             HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_up[k], 0));
             int rc = batch_run_range(h, h->d_host_pcm.p, pcm_samples_total, h->d_host_out.p, u0, u1);
-            if (rc != MFX_OK) {
-                (void)hipDeviceSynchronize();
-                return rc;
-            }
+            if (rc != MFX_OK) return rc;
             HIP_TRY(h, hipEventRecord(h->ev_run[k], h->stream));
             HIP_TRY(h, hipStreamWaitEvent(h->stream_dn, h->ev_run[k], 0));
             const int64_t r0 = h->utt_row[u0], r1 = u1 < h->n_utt ? h->utt_row[u1] : h->total_rows;
             if (r1 > r0)
                 HIP_TRY(h, hipMemcpyAsync(out + r0 * h->width, h->d_host_out.p + r0 * h->width,
                                           (size_t)(r1 - r0) * h->width * sizeof(float), hipMemcpyDeviceToHost, h->stream_dn));
+            return MFX_OK;
+        };
+        for (int k = 0; k < K; ++k) {
+            const int rc = run_slice(k);
+            if (rc != MFX_OK) { // nothing may still read `pcm` or write `out` once we have returned
+                (void)hipStreamSynchronize(h->stream_up);
+                (void)hipStreamSynchronize(h->stream);
+                (void)hipStreamSynchronize(h->stream_dn);
+                return rc;
+            }
         }
         HIP_TRY(h, hipStreamSynchronize(h->stream_dn));
         return mfx_synchronize(h);

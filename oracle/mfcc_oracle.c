@@ -53,9 +53,11 @@ int orc_output_width(int num_banks, int ceps_len, int want_c0, int dyn)
     return cols;
 }
 
-/* mfcccpu.cpp:21-22 */
-static float hz2mel(float f) { return 1127 * logf(f / 700 + 1); }
-static float mel2hz(float f) { return 700 * (expf(f / 1127) - 1); }
+/* mfcccpu.cpp:21-22.  `dbl` selects how the reference's UNQUALIFIED libm names bind when their argument is a
+ * float: 0 = the float overloads (MSVC, the reference's own toolchain -- the checker's default), 1 = the C double
+ * functions (g++ with <cmath> only, i.e. how oracle/_ref/libref_mfcccpu.so computes). */
+static float hz2mel(float f, int dbl) { return dbl ? (float)(1127 * log((double)(f / 700 + 1))) : 1127 * logf(f / 700 + 1); }
+static float mel2hz(float f, int dbl) { return dbl ? (float)(700 * (exp((double)(f / 1127)) - 1)) : 700 * (expf(f / 1127) - 1); }
 
 /* ------------------------------------------------------------------------------------------ */
 /* stage functions                                                                            */
@@ -86,9 +88,10 @@ void orc_delta_apply(const float *data, int dim, int window_count, int delta_siz
         }
 }
 
-/* normalizercpu.cpp:22-89.  Statistics in double, applied in float. */
-void orc_normalize(int norm_type, float *data, int dim, int window_count, int use_last_stats,
-                   float *mean, float *var, float *minmax)
+/* normalizercpu.cpp:22-89.  Statistics in double, applied in float.  abs_int: the unqualified abs() of
+ * normalizercpu.cpp:66 bound to int abs(int) (g++) instead of the float overload (MSVC). */
+static void normalize_impl(int norm_type, float *data, int dim, int window_count, int use_last_stats,
+                           float *mean, float *var, float *minmax, int abs_int)
 {
     if (!use_last_stats) {
         switch (norm_type) {
@@ -123,6 +126,10 @@ void orc_normalize(int norm_type, float *data, int dim, int window_count, int us
                 }
                 mean[i] = (float)(sum / window_count);
                 float a = fabsf(minv - mean[i]), b = fabsf(maxv - mean[i]);
+                if (abs_int) {
+                    a = (float)abs((int)(minv - mean[i]));
+                    b = (float)abs((int)(maxv - mean[i]));
+                }
                 minmax[i] = 1.f / (a > b ? a : b);
             }
             break;
@@ -148,6 +155,12 @@ void orc_normalize(int norm_type, float *data, int dim, int window_count, int us
     default:
         break;
     }
+}
+
+void orc_normalize(int norm_type, float *data, int dim, int window_count, int use_last_stats,
+                   float *mean, float *var, float *minmax)
+{
+    normalize_impl(norm_type, data, dim, window_count, use_last_stats, mean, var, minmax, 0);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -357,6 +370,7 @@ struct orc_mfcc {
     /* NormalizerCPU stats x3 (normalizercpu.h:7-9): [static, delta, acc] */
     float *n_mean[3], *n_var[3], *n_minmax[3];
     int bug_compat;
+    int libm_double; /* see hz2mel */
     rfft32_plan *plan32;
 };
 
@@ -370,11 +384,15 @@ static void refresh_filters(orc_mfcc *o)
     float *centers = (float *)malloc(sizeof(float) * (nb + 2));
     memset(o->filters, 0, sizeof(float) * 2 * W2);
 
-    float minmel = hz2mel(o->cfg.low_freq), maxmel = hz2mel(o->cfg.high_freq);
+    const int dbl = o->libm_double;
+    float minmel = hz2mel(o->cfg.low_freq, dbl), maxmel = hz2mel(o->cfg.high_freq, dbl);
     for (int i = 0; i < nb + 2; i++) {
-        float f = mel2hz(i / (float)(nb + 1) * (maxmel - minmel) + minmel);
+        float f = mel2hz(i / (float)(nb + 1) * (maxmel - minmel) + minmel, dbl);
         float w = 2 * (float)M_PI * f / sr;
-        w = w + 2 * atanf(((1 - o->alpha) * sinf(w)) / (1 - (1 - o->alpha) * cosf(w)));
+        if (dbl) /* float * double -> double all the way to the assignment */
+            w = (float)(w + 2 * atan(((1 - o->alpha) * sin((double)w)) / (1 - (1 - o->alpha) * cos((double)w))));
+        else
+            w = w + 2 * atanf(((1 - o->alpha) * sinf(w)) / (1 - (1 - o->alpha) * cosf(w)));
         centers[i] = sr * w / (2 * (float)M_PI);
         o->filter_beg[i] = (int)floor((double)(centers[i] * W2 / sr) + 0.5);
     }
@@ -505,6 +523,11 @@ void orc_destroy(orc_mfcc *o)
 }
 
 void orc_set_bug_compat(orc_mfcc *o, int on) { o->bug_compat = on; }
+void orc_set_libm_binding(orc_mfcc *o, int use_double)
+{
+    o->libm_double = use_double != 0;
+    refresh_filters(o);
+}
 void orc_set_alpha(orc_mfcc *o, float alpha) { o->alpha = alpha; } /* parambase.h:25 */
 int orc_get_input_buffer_size(const orc_mfcc *o) { return o->input_buffer_size; }
 int orc_estimated_window_count(const orc_mfcc *o, int samples) { return orc_ewc(samples, o->window_size, o->shift); }
@@ -609,13 +632,15 @@ static void do_filter(orc_mfcc *o, int window_count)
         int lastf = o->filter_beg[nb + 1];
         for (int j = o->filter_beg[0]; j <= lastf; j++) {
             const float *c = o->fft + 2 * ((size_t)W2 * i + j);
-            float v = sqrtf(c[0] * c[0] + c[1] * c[1]) / W2;
+            float v = o->libm_double ? (float)(sqrt((double)(c[0] * c[0] + c[1] * c[1])) / W2)
+                                     : sqrtf(c[0] * c[0] + c[1] * c[1]) / W2;
             while (curf + 1 <= nb + 1 && j == o->filter_beg[curf + 1]) {
                 curf++;
                 if (curf >= 2) {
                     int sumidx = curf % 2;
                     float s = sum[sumidx];
-                    o->mel[(size_t)nb * i + curf - 2] = logf(s > 1e-30f ? s : 1e-30f);
+                    s = s > 1e-30f ? s : 1e-30f;
+                    o->mel[(size_t)nb * i + curf - 2] = o->libm_double ? (float)log((double)s) : logf(s);
                     sum[sumidx] = 0;
                 }
             }
@@ -636,6 +661,11 @@ static void do_dct(orc_mfcc *o, int window_count)
             o->mfcc[(size_t)dl * i + j] = sum;
         }
 }
+
+/* test hooks: MfccCpu::filter / MfccCpu::dct on the first `rows` rows of the spectrum buffer (which the caller may have
+ * filled through orc_tap_fft) -- the counterpart of oracle/ref_mfcccpu_shim.cpp's refm_filter / refm_dct */
+void orc_stage_filter(orc_mfcc *o, int rows) { do_filter(o, rows); }
+void orc_stage_dct(orc_mfcc *o, int rows) { if (o->ceps_len > 0) do_dct(o, rows); }
 
 /* mfcccpu.cpp:234-263 */
 static void do_delta(orc_mfcc *o, int window_count, int first_call, int last_call)
@@ -678,16 +708,16 @@ static void do_normalize(orc_mfcc *o, int window_count, int use_last_stats)
     const int cols = cols_of(o);
     float *src = o->ceps_len > 0 ? o->mfcc : o->mel;
     if (o->cfg.norm_after_dyn) {
-        orc_normalize(norm, src + (size_t)static_offset_rows(o) * cols, cols, window_count, use_last_stats,
-                      o->n_mean[0], o->n_var[0], o->n_minmax[0]);
+        normalize_impl(norm, src + (size_t)static_offset_rows(o) * cols, cols, window_count, use_last_stats,
+                      o->n_mean[0], o->n_var[0], o->n_minmax[0], o->libm_double);
         if (o->cfg.dyn == ORC_DYN_DELTA || o->cfg.dyn == ORC_DYN_ACC)
-            orc_normalize(norm, o->delta_out + (size_t)o->delta_l2 * cols, cols, window_count, use_last_stats,
-                          o->n_mean[1], o->n_var[1], o->n_minmax[1]);
+            normalize_impl(norm, o->delta_out + (size_t)o->delta_l2 * cols, cols, window_count, use_last_stats,
+                          o->n_mean[1], o->n_var[1], o->n_minmax[1], o->libm_double);
         if (o->cfg.dyn == ORC_DYN_ACC)
-            orc_normalize(norm, o->acc_out, cols, window_count, use_last_stats, o->n_mean[2], o->n_var[2],
-                          o->n_minmax[2]);
+            normalize_impl(norm, o->acc_out, cols, window_count, use_last_stats, o->n_mean[2], o->n_var[2],
+                          o->n_minmax[2], o->libm_double);
     } else
-        orc_normalize(norm, src, cols, window_count, use_last_stats, o->n_mean[0], o->n_var[0], o->n_minmax[0]);
+        normalize_impl(norm, src, cols, window_count, use_last_stats, o->n_mean[0], o->n_var[0], o->n_minmax[0], o->libm_double);
 }
 
 /* mfcccpu.cpp:371-425 */

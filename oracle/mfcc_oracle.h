@@ -77,6 +77,10 @@ int orc_fft_size(const orc_mfcc *o);
  * uses (was_flushed() ? 0 : D), which reproduces reference behaviour B1 for files
  * consumed by exactly one set_input.  When zero the flush block reads the correct rows. */
 void orc_set_bug_compat(orc_mfcc *o, int on);
+/* How the reference's unqualified log/exp/atan/sin/cos/sqrt on floats (mfcccpu.cpp:21-22,37,203,212) bind:
+ * 0 (default) = float overloads, as under the reference's own toolchain (MSVC); 1 = the C double functions, as
+ * under g++ -- the binding of oracle/_ref/libref_mfcccpu.so, against which this mode is compared bit for bit. */
+void orc_set_libm_binding(orc_mfcc *o, int use_double);
 
 /* stage taps (valid after set_input/flush resp. apply), for stage-by-stage parity tests */
 const float *orc_tap_frames(const orc_mfcc *o);   /* [window_limit][W2]            */
@@ -89,6 +93,11 @@ const float *orc_tap_dct_matrix(const orc_mfcc *o); /* [num_banks][dct_len] or N
 /* normaliser statistics after apply(): group 0/1/2 = static/delta/delta-delta instance, which 0 = mean, 1 = multiplier;
  * cols floats each (normalizercpu.cpp:22-67) */
 const float *orc_tap_norm_stats(const orc_mfcc *o, int group, int which);
+
+/* MfccCpu::filter (mfcccpu.cpp:192-220) / MfccCpu::dct (:222-232) alone, on the first `rows` rows of the spectrum
+ * buffer orc_tap_fft points at (tests write caller-made spectra there) */
+void orc_stage_filter(orc_mfcc *o, int rows);
+void orc_stage_dct(orc_mfcc *o, int rows);
 
 /* ---- standalone stage functions (compared 1:1 with the real reference objects in oracle/_ref) ---- */
 

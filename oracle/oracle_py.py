@@ -102,6 +102,9 @@ def lib(path=None):
     L.orc_window_limit.argtypes = [C.c_void_p]
     L.orc_fft_size.argtypes = [C.c_void_p]
     L.orc_set_bug_compat.argtypes = [C.c_void_p, C.c_int]
+    L.orc_set_libm_binding.argtypes = [C.c_void_p, C.c_int]
+    L.orc_stage_filter.argtypes = [C.c_void_p, C.c_int]
+    L.orc_stage_dct.argtypes = [C.c_void_p, C.c_int]
     for name in ("frames", "fft", "mel", "mfcc", "filters", "dct_matrix"):
         fn = getattr(L, "orc_tap_" + name)
         fn.restype, fn.argtypes = fp, [C.c_void_p]
@@ -144,13 +147,15 @@ ERRORS = {
 class OracleMfcc:
     """Object mirror of the reference's MfccCpu (mfcccpu.h:14-67) on top of liboracle.so."""
 
-    def __init__(self, cfg, window=None, bug_compat=True, libpath=None):
+    def __init__(self, cfg, window=None, bug_compat=True, libpath=None, libm_double=False):
         self.L = lib(libpath)
         self.cfg = cfg
         self.h = self.L.orc_create(C.byref(cfg))
         if not self.h:
             raise RuntimeError("orc_create failed")
         self.L.orc_set_bug_compat(self.h, int(bug_compat))
+        if libm_double:   # g++ binding of the reference's unqualified libm calls (see mfcc_oracle.h)
+            self.L.orc_set_libm_binding(self.h, 1)
         if window is None:
             window = reference_window(cfg.window_size)
         self.set_window(window)
@@ -217,6 +222,21 @@ class OracleMfcc:
         per_row = {"frames": W2, "fft": 2 * W2, "mel": nb, "mfcc": dl}[name]
         p = getattr(self.L, "orc_tap_" + name)(self.h)
         return np.ctypeslib.as_array(p, shape=(rows * per_row,)).reshape(rows, per_row).copy()
+
+    def load_fft(self, spec):
+        """Put caller-made spectra [rows][W2/2+1] complex64 into the spectrum buffer (rows of W2 complex values)."""
+        spec = np.asarray(spec, dtype=np.complex64)
+        W2, rows = self.fft_size, spec.shape[0]
+        assert spec.shape[1] == W2 // 2 + 1
+        buf = np.ctypeslib.as_array(self.L.orc_tap_fft(self.h), shape=(rows * W2 * 2,)).reshape(rows, W2, 2)
+        buf[:, :spec.shape[1], 0] = spec.real
+        buf[:, :spec.shape[1], 1] = spec.imag
+
+    def filter(self, rows):
+        self.L.orc_stage_filter(self.h, int(rows))
+
+    def dct(self, rows):
+        self.L.orc_stage_dct(self.h, int(rows))
 
     def norm_stats(self):
         """(mean, multiplier) of the normaliser instances after apply(): [groups][2][cols]; groups = 1 when the
@@ -337,3 +357,201 @@ def ref():
     R.ref_norm_normalize.argtypes = [vp, fp, C.c_int, C.c_int]
     _ref = R
     return R
+
+
+# ---------------------------------------------------------------------------------------------
+# the real MfccCpu member functions (oracle/_ref/libref_mfcccpu.so, see oracle/ref_mfcccpu_shim.cpp)
+# ---------------------------------------------------------------------------------------------
+_refm = None
+
+
+def refm_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_mfcccpu.so"))
+
+
+def refm():
+    global _refm
+    if _refm is not None:
+        return _refm
+    p = os.path.join(_HERE, "_ref", "libref_mfcccpu.so")
+    if not os.path.exists(p):
+        raise RuntimeError("oracle/_ref/libref_mfcccpu.so not built (needs /root/reference): make -C oracle ref")
+    R = C.CDLL(p)
+    fp, ip, sp, vp = C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_short), C.c_void_p
+    R.refm_new.restype = vp
+    R.refm_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int,
+                           C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    R.refm_free.argtypes = [vp]
+    for n in ("input_buffer_size", "window_limit", "cap_rows", "fft_size", "output_width", "was_flushed", "last_block"):
+        getattr(R, "refm_" + n).argtypes = [vp]
+    R.refm_ewc.argtypes = [vp, C.c_int]
+    R.refm_set_window.argtypes = [vp, fp]
+    R.refm_set_alpha.argtypes = [vp, C.c_float]
+    R.refm_set_input_nofft.argtypes = [vp, sp, C.c_int, ip]
+    R.refm_flush_nofft.argtypes = [vp, ip]
+    for n in ("data", "fft", "mel", "mfcc", "dct_matrix", "filters", "delta_in", "delta_out", "acc_out"):
+        fn = getattr(R, "refm_" + n)
+        fn.restype, fn.argtypes = fp, [vp]
+    R.refm_filter_beg.restype, R.refm_filter_beg.argtypes = ip, [vp]
+    R.refm_norm_stats.restype, R.refm_norm_stats.argtypes = fp, [vp, C.c_int, C.c_int]
+    R.refm_refresh_filters.argtypes = [vp]
+    R.refm_filter.argtypes = [vp, C.c_int]
+    R.refm_dct.argtypes = [vp, C.c_int]
+    R.refm_do_delta.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    R.refm_normalize.argtypes = [vp, C.c_int, C.c_int]
+    R.refm_apply.argtypes = [vp]
+    R.refm_get_output_data.argtypes = [vp, fp, C.c_int]
+    _refm = R
+    return R
+
+
+class RefMfccCpu:
+    """The reference's MfccCpu, driven through the call sequence of OracleMfcc.  refresh_filters / filter / dct /
+    do_delta / normalize / apply / get_output_data and the segmenter, delta and normaliser members are the
+    reference's compiled code; the transform at the FFTW call site (mfcccpu.cpp:187-190) is the double-precision DFT
+    rounded to float that the oracle's fft_mode 0 also uses (orc_rfft_rows), written into the object's m_fft."""
+
+    def __init__(self, cfg, window=None):
+        self.R = refm()
+        self.cfg = cfg
+        self.h = self.R.refm_new(cfg.input_buffer_size, cfg.window_size, cfg.shift, cfg.num_banks, cfg.sample_rate,
+                                 cfg.low_freq, cfg.high_freq, cfg.ceps_len, cfg.want_c0, cfg.lift_coef, cfg.norm,
+                                 cfg.dyn, cfg.delta_l1, cfg.delta_l2, cfg.norm_after_dyn)
+        self.W2 = self.R.refm_fft_size(self.h)
+        self.cap = self.R.refm_cap_rows(self.h)
+        if window is None:
+            window = reference_window(cfg.window_size)
+        self.set_window(window)
+
+    def close(self):
+        if self.h:
+            self.R.refm_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise RuntimeError(ERRORS.get(rc, "error %d" % rc))
+        return rc
+
+    def set_window(self, w):
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        assert w.size == self.cfg.window_size
+        self.R.refm_set_window(self.h, _fp(w))
+
+    def _fft(self, rows):
+        assert rows <= self.cap
+        lib().orc_rfft_rows(self.R.refm_data(self.h), self.R.refm_fft(self.h), self.W2, rows, 0)
+
+    def set_input(self, pcm):
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        wcnd = C.c_int(0)
+        n = self._chk(self.R.refm_set_input_nofft(self.h, _sp(pcm), pcm.size, C.byref(wcnd)))
+        if n > 0:
+            self._fft(wcnd.value)
+        return n
+
+    def flush(self):
+        wcnd = C.c_int(0)
+        n = self._chk(self.R.refm_flush_nofft(self.h, C.byref(wcnd)))
+        if n > 0:
+            self._fft(wcnd.value)
+        return n
+
+    def set_alpha(self, a):
+        self.R.refm_set_alpha(self.h, float(a))
+
+    def apply(self):
+        self._chk(self.R.refm_apply(self.h))
+
+    @property
+    def width(self):
+        return self.R.refm_output_width(self.h)
+
+    @property
+    def input_buffer_size(self):
+        return self.R.refm_input_buffer_size(self.h)
+
+    @property
+    def window_limit(self):
+        return self.R.refm_window_limit(self.h)
+
+    @property
+    def fft_size(self):
+        return self.W2
+
+    def estimated_window_count(self, samples):
+        return self.R.refm_ewc(self.h, int(samples))
+
+    def get_output_data(self, n):
+        out = np.empty((max(n, 0), self.width), dtype=np.float32)
+        if n > 0:
+            self._chk(self.R.refm_get_output_data(self.h, _fp(out), n))
+        return out
+
+    def tap(self, name, rows):
+        W2, nb = self.W2, self.cfg.num_banks
+        dl = self.cfg.ceps_len + (1 if self.cfg.want_c0 else 0)
+        per_row = {"frames": W2, "fft": 2 * W2, "mel": nb, "mfcc": dl}[name]
+        fn = {"frames": self.R.refm_data, "fft": self.R.refm_fft, "mel": self.R.refm_mel, "mfcc": self.R.refm_mfcc}[name]
+        return np.ctypeslib.as_array(fn(self.h), shape=(rows * per_row,)).reshape(rows, per_row).copy()
+
+    def load_fft(self, spec):
+        """Put caller-made spectra [rows][W2/2+1] complex64 into m_fft (rows of W2 complex, as FFTW's odist)."""
+        spec = np.asarray(spec, dtype=np.complex64)
+        rows = spec.shape[0]
+        assert rows <= self.cap and spec.shape[1] == self.W2 // 2 + 1
+        buf = np.ctypeslib.as_array(self.R.refm_fft(self.h), shape=(self.cap * self.W2 * 2,)).reshape(self.cap, self.W2, 2)
+        buf[:rows, :spec.shape[1], 0] = spec.real
+        buf[:rows, :spec.shape[1], 1] = spec.imag
+
+    def filter(self, rows):
+        self.R.refm_filter(self.h, int(rows))
+
+    def dct(self, rows):
+        self.R.refm_dct(self.h, int(rows))
+
+    def norm_stats(self):
+        dl = self.cfg.ceps_len + (1 if self.cfg.want_c0 else 0)
+        cols = dl if self.cfg.ceps_len > 0 else self.cfg.num_banks
+        groups = (1 + self.cfg.dyn) if self.cfg.norm_after_dyn else 1
+        out = np.ones((groups, 2, cols), np.float32)
+        which = {NORM_CMN: None, NORM_CVN: 1, NORM_MINMAX: 2}[self.cfg.norm]
+        for g in range(groups):
+            out[g, 0] = np.ctypeslib.as_array(self.R.refm_norm_stats(self.h, g, 0), shape=(cols,))
+            if which is not None:
+                out[g, 1] = np.ctypeslib.as_array(self.R.refm_norm_stats(self.h, g, which), shape=(cols,))
+        return out
+
+    def tables(self):
+        W2, nb = self.W2, self.cfg.num_banks
+        dl = self.cfg.ceps_len + (1 if self.cfg.want_c0 else 0)
+        t = {
+            "filters": np.ctypeslib.as_array(self.R.refm_filters(self.h), shape=(2 * W2,)).reshape(2, W2).copy(),
+            "filter_beg": np.ctypeslib.as_array(self.R.refm_filter_beg(self.h), shape=(nb + 2,)).copy(),
+        }
+        if self.cfg.ceps_len > 0:
+            t["dct_matrix"] = np.ctypeslib.as_array(self.R.refm_dct_matrix(self.h), shape=(nb * dl,)).reshape(nb, dl).copy()
+        return t
+
+
+def run_reference_utterance(cfg, pcm, window=None, alpha=1.0, block_samples=0):
+    """ASR_OCL.cpp:149-301 over one utterance on the REAL MfccCpu -> [frames][width] (B1 and all)."""
+    m = RefMfccCpu(cfg, window)
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    blk = m.input_buffer_size if block_samples <= 0 else min(block_samples, m.input_buffer_size)
+    rows = []
+    for pos in range(0, pcm.size, blk):
+        n = m.set_input(pcm[pos:pos + blk])
+        if n > 0:
+            m.set_alpha(alpha)
+            m.apply()
+            rows.append(m.get_output_data(n))
+    n = m.flush()
+    if n > 0:
+        m.set_alpha(alpha)
+        m.apply()
+        rows.append(m.get_output_data(n))
+    m.close()
+    return np.concatenate(rows) if rows else np.zeros((0, m.width), np.float32)

@@ -9,6 +9,13 @@ Files
   ref_stage_vectors.npz    inputs and outputs of the REAL reference objects that build without
                            FFTW (SegmenterCPU, DeltaCPU, NormalizerCPU, ParamBase/MfccBase), driven
                            through oracle/_ref/libref_stages.so on seeded inputs.
+  ref_mfcccpu_vectors.npz  outputs of the REAL MfccCpu member functions (refresh_filters, filter, dct, do_delta, normalize,
+                           apply, get_output_data: /root/reference/mfcccpu.cpp compiled in place into
+                           oracle/_ref/libref_mfcccpu.so, its FFTW-calling constructor / fft() dropped at link time; the
+                           transform at that call site is the double-precision DFT rounded to float) for every case of
+                           tests/refcases.py: rows, frames per call, mel tables, and filter()/dct() on synthetic spectra.
+                           g++ binds the reference's unqualified libm calls to the double functions; the vectors are
+                           therefore those of a g++ build of the reference (see oracle/mfcc_oracle.h, orc_set_libm_binding).
   c1_a0001_oracle.npz      features of BASELINE config C1 (a0001.wav, 26 mel, 13 MFCC + d + dd)
                            from this repo's oracle (oracle/mfcc_oracle.c).  NOT reference output:
                            mfcccpu.cpp needs libfftw3f and cannot be built here, and the reference
@@ -121,7 +128,48 @@ def c1_oracle():
     print("wrote c1_a0001_oracle.npz", multi.shape, single.shape, dflt.shape)
 
 
+def ref_mfcccpu_vectors():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import refcases as RC
+    out = {}
+    for name, c in RC.cases().items():
+        pcm = RC.load_pcm(c["pcm"])
+        m = O.RefMfccCpu(RC.make_cfg(O, c), RC.case_window(O, c))
+        rows, counts = RC.drive(m, pcm, c["alpha"])
+        t = m.tables()
+        out[name + "/rows"], out[name + "/counts"] = rows, counts
+        out[name + "/filter_beg"], out[name + "/filters"] = t["filter_beg"], t["filters"]
+        if "dct_matrix" in t:
+            out[name + "/dct_matrix"] = t["dct_matrix"]
+        m.close()
+    # filter() and dct() alone on caller-made spectra (incl. an all-zero row: the 1e-30 floor, and a huge one)
+    rng = np.random.default_rng(20261004)
+    for tag, W, nb, nc, sr, a in (("c2", 400, 40, 13, 16000.0, 1.0), ("c3", 1024, 80, 13, 16000.0, 0.9),
+                                  ("c5", 1102, 128, 40, 44100.0, 1.1)):
+        cfg = O.make_config(20 * W, window_size=W, shift=W // 2, num_banks=nb, sample_rate=sr, ceps_len=nc, dyn=O.DYN_NONE)
+        m = O.RefMfccCpu(cfg)
+        W2, rows = m.fft_size, 6
+        spec = (rng.standard_normal((rows, W2 // 2 + 1)) + 1j * rng.standard_normal((rows, W2 // 2 + 1))).astype(np.complex64)
+        spec *= np.float32(50.0)
+        spec[1] = 0
+        spec[2] *= np.float32(1e6)
+        spec[3] *= np.float32(1e-12)
+        m.set_alpha(a)
+        m.load_fft(spec)
+        m.filter(rows)
+        m.dct(rows)
+        out["stage_%s/spec" % tag], out["stage_%s/alpha" % tag] = spec, np.float32(a)
+        out["stage_%s/mel" % tag], out["stage_%s/mfcc" % tag] = m.tap("mel", rows), m.tap("mfcc", rows)
+        m.close()
+    np.savez_compressed(os.path.join(HERE, "ref_mfcccpu_vectors.npz"), **out)
+    print("wrote ref_mfcccpu_vectors.npz with", len(out), "arrays")
+
+
 if __name__ == "__main__":
+    if O.refm_available():
+        ref_mfcccpu_vectors()
+    else:
+        print("oracle/_ref/libref_mfcccpu.so missing: ref_mfcccpu_vectors.npz not regenerated")
     if O.ref_available():
         ref_stage_vectors()
     else:
