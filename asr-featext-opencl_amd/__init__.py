@@ -10,6 +10,7 @@ constructors raise.  (The directory name is not an importable identifier; load i
 ``sys.path`` and use ``importlib.import_module("asr-featext-opencl_amd")``.)
 """
 from . import mfcc  # noqa: F401
+from . import sharding  # noqa: F401
 from .mfcc import (  # noqa: F401
     DYN_ACC,
     DYN_DELTA,

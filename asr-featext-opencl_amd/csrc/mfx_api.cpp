@@ -140,7 +140,7 @@ struct mfx_handle {
     bool batch_aligned = true;
     // fused delta stage of the 512-point kernel: per-block chunk lists (own rows + halo) and delta tiles
     int num_cus = 256;
-    bool fuse_delta_enabled = false; // MFX_FUSE_DELTA=1 opts in to the fused delta stage (measured 1-2 % slower
+    bool fuse_delta_enabled = false; // mfx_config.engine & MFX_ENGINE_FUSE_DELTA opts in to the fused delta stage (measured 1-2 % slower
                                      // than front end + k_delta on C2; kept tested, off by default)
     bool fuse_plan = false;
     int f_blocks = 0, f_done_words = 0;
@@ -523,16 +523,13 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
     }
     h->spec_pitch = ((h->W2 / 2 + 1) + 3) & ~3;
     h->fast512 = front512_supported(h->W2, h->W, h->nb, h->cols, h->channels);
-    {
-        const char *e = std::getenv("MFX_NO_FRONT1024"); // dev: keep k_front_reg for such configurations
-        h->fast1024 = !(e && e[0] == '1') && front1024_supported(h->W2, h->W, h->nb, h->cols, h->channels, h->ceps);
-    }
+    h->fast1024 = !(h->cfg.engine & MFX_ENGINE_NO_FRONT1024) &&
+                  front1024_supported(h->W2, h->W, h->nb, h->cols, h->channels, h->ceps);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, hip_device) == hipSuccess && prop.multiProcessorCount > 0)
             h->num_cus = prop.multiProcessorCount;
-        const char *e = std::getenv("MFX_FUSE_DELTA");
-        if (e) h->fuse_delta_enabled = e[0] == '1';
+        h->fuse_delta_enabled = (h->cfg.engine & MFX_ENGINE_FUSE_DELTA) != 0;
     }
     h->nm16 = (h->W + 31) / 32;
 
@@ -1470,10 +1467,10 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
     // The 512-point kernel deals chunks to the 16 waves of each block as they become free; with 16-frame
     // chunks a wave can sit idle for most of a chunk time (~34 us on C2) at the end of the launch.  The last two
     // chunks of every wave of the grid are therefore cut into 4-frame pieces (one kernel iteration each).
-    const char *ts = std::getenv("MFX_TAIL_SPLIT");
-    if ((h->fast512 || (h->fast1024 && h->fused_ok)) && !(ts && ts[0] == '0')) {
+    const int ts = h->cfg.tail_split;
+    if ((h->fast512 || (h->fast1024 && h->fused_ok)) && ts >= 0) {
         const size_t n = h->h_chunks.size();
-        const size_t tail = std::min<size_t>(n, (size_t)(ts && ts[0] > '0' ? ts[0] - '0' : 2) * 16 * h->num_cus);
+        const size_t tail = std::min<size_t>(n, (size_t)(ts > 0 ? std::min(ts, 64) : 2) * 16 * h->num_cus);
         if (n >= 4 * tail) { // only when the launch is long enough for the tail to matter
             std::vector<Chunk> cut;
             std::vector<int32_t> cut_utt;

@@ -45,7 +45,9 @@ class MfxConfig(C.Structure):
         ("channels", C.c_int32),
         ("bug_compat", C.c_int32),
         ("batch_norm_stats", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("engine", C.c_int32),
+        ("tail_split", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -229,6 +231,9 @@ def reference_window(window_size):
     return (inner.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
 
 
+ENGINE_NO_FRONT1024, ENGINE_FUSE_DELTA = 1, 2     # mfx_config.engine bits (include/mfx.h)
+
+
 class MfccHip:
     """Python mirror of ``class MfccHip : public MfccBase`` (host/afet_param.h).
 
@@ -238,13 +243,14 @@ class MfccHip:
 
     def __init__(self, input_buffer_size, window_size, shift, num_banks, sample_rate, low_freq, high_freq,
                  ceps_len, want_c0, lift_coef, norm=NORM_NONE, dyn=DYN_NONE, delta_l1=1, delta_l2=1,
-                 norm_after_dyn=True, device=0, fft_size=0, channels=1, bug_compat=True, batch_norm_stats=0):
+                 norm_after_dyn=True, device=0, fft_size=0, channels=1, bug_compat=True, batch_norm_stats=0, engine=0,
+                 tail_split=0):
         self._L = load_library()
         self.cfg = MfxConfig(int(input_buffer_size), int(window_size), int(shift), int(num_banks),
                              float(sample_rate), float(low_freq), float(high_freq), int(ceps_len),
                              int(bool(want_c0)), float(lift_coef), int(norm), int(dyn), int(delta_l1),
                              int(delta_l2), int(bool(norm_after_dyn)), int(fft_size), int(channels),
-                             int(bool(bug_compat)), int(batch_norm_stats))
+                             int(bool(bug_compat)), int(batch_norm_stats), int(engine), int(tail_split))
         h = C.c_void_p()
         rc = self._L.mfx_create(C.byref(self.cfg), int(device), C.byref(h))
         if rc != 0:

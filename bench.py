@@ -11,6 +11,12 @@ only for the barrier and the max-over-ranks of the timing).
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+  --workload C2|C3|C4|C5|R|T   (R = the reference main()'s own defaults, ASR_OCL.cpp:560: 15 banks, 12 MFCC + c0, CVN)
+  --scaling weak|strong         weak (default): every rank runs the workload's utterance count; strong: ONE job of
+                                `n_utt_total` utterances (C4: BASELINE configs[3], 100 000) sharded round-robin over the
+                                ranks by asr-featext-opencl_amd/sharding.py, every utterance's PCM a function of its index
+                                only, so that N = 1, 2, 4, 8 compute the same job
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -32,11 +38,19 @@ WORKLOADS = {
     # name: (n_utt, utt_samples, sample_rate, W, S, fft, nb, nc, dyn)
     "C2": dict(n_utt=1000, utt_samples=160000, sr=16000.0, W=400, S=160, fft=0, nb=40, nc=13, dyn=2,
                desc="1000 synthetic 16 kHz utterances x 10 s, 25 ms/10 ms, 512-pt FFT, 40 mel, 13 MFCC + d + dd"),
-    "C4": dict(n_utt=12500, utt_samples=160000, sr=16000.0, W=400, S=160, fft=0, nb=40, nc=13, dyn=2,
+    "C4": dict(n_utt=12500, n_utt_total=100000, utt_samples=160000, sr=16000.0, W=400, S=160, fft=0, nb=40, nc=13, dyn=2,
                desc="per-GPU share of 100 000 synthetic 16 kHz utterances x 10 s sharded round-robin over 8 GPUs "
-                    "(12 500 utterances, 4 GB of PCM per GPU), 512-pt FFT, 40 mel, 13 MFCC + d + dd"),
-    "T": dict(n_utt=8, utt_samples=16000, sr=16000.0, W=400, S=160, fft=0, nb=40, nc=13, dyn=2,
-              desc="tiny test workload: 8 synthetic 16 kHz utterances x 1 s (launch-path tests only)"),
+                    "(12 500 utterances, 4 GB of PCM per GPU), 512-pt FFT, 40 mel, 13 MFCC + d + dd",
+               desc_strong="100 000 synthetic 16 kHz utterances x 10 s sharded round-robin over the GPUs, 512-pt FFT, "
+                           "40 mel, 13 MFCC + d + dd"),
+    "T": dict(n_utt=8, n_utt_total=13, utt_samples=16000, sr=16000.0, W=400, S=160, fft=0, nb=40, nc=13, dyn=2,
+              desc="tiny test workload: 8 synthetic 16 kHz utterances x 1 s (launch-path tests only)",
+              desc_strong="tiny test job: 13 synthetic 16 kHz utterances x 1 s sharded round-robin over the GPUs"),
+    # the reference main()'s own defaults (ASR_OCL.cpp:560): 15 banks, 12 MFCC + c0, CVN, no deltas -- the configuration in
+    # which a quarter of the reference's CPU profile is the normaliser (output_files/out.txt)
+    "R": dict(n_utt=1000, utt_samples=160000, sr=16000.0, W=400, S=160, fft=0, nb=15, nc=12, c0=True, dyn=0, norm=2,
+              desc="reference main() defaults (ASR_OCL.cpp:560): 1000 synthetic 16 kHz utterances x 10 s, 512-pt FFT, "
+                   "15 mel, 12 MFCC + c0, CVN per utterance block, no deltas"),
     "C3": dict(n_utt=1, utt_samples=57600000, sr=16000.0, W=400, S=160, fft=1024, nb=80, nc=13, dyn=0,
                desc="one 1-hour 16 kHz stream, 1024-pt FFT, 80 mel, 13 MFCC"),
     "C5": dict(n_utt=200, utt_samples=441000, sr=44100.0, W=1102, S=441, fft=0, nb=128, nc=40, dyn=2, channels=2,
@@ -61,6 +75,69 @@ def synth_pcm_torch(torch, n_utt, utt_samples, sr, seed, device):
         pcm[u0:u1] = torch.clamp(torch.round(x), -32768, 32767).to(torch.int16)
         del x
     return pcm
+
+
+def synth_pcm_by_index(torch, utt_ids, utt_samples, sr, device):
+    """The same signal model with every utterance a function of its GLOBAL index only (counter-based: a 32-bit integer hash
+    of (utterance, sample) -> two uniforms -> Box-Muller), so that any sharding of one job sees the same data.
+    utt_ids: int64 tensor/array of global utterance indices; returns int16 [len(utt_ids), utt_samples]."""
+    ids = torch.as_tensor(np.asarray(utt_ids, dtype=np.int64), device=device)
+    pcm = torch.empty((ids.numel(), utt_samples), dtype=torch.int16, device=device)
+    n = torch.arange(utt_samples, device=device, dtype=torch.int64)
+    nf = n.to(torch.float32)
+    M = 0xFFFFFFFF
+
+    def mix(x):   # lowbias32 (public domain integer hash), on int64 lanes masked to 32 bits
+        x = x & M
+        x = ((x ^ (x >> 16)) * 0x7FEB352D) & M
+        x = ((x ^ (x >> 15)) * 0x846CA68B) & M
+        return x ^ (x >> 16)
+
+    slab = max(1, min(ids.numel(), (1 << 24) // max(utt_samples, 1)))
+    for u0 in range(0, ids.numel(), slab):
+        u = ids[u0:u0 + slab]
+        key = mix((0x5EED0000 + u) & M)[:, None]
+        h1 = mix(key ^ mix(2 * n + 1)[None, :])
+        h2 = mix(key ^ mix(2 * n + 2)[None, :])
+        u1 = (h1.to(torch.float32) + 1.0) * (1.0 / 4294967296.0)
+        u2 = h2.to(torch.float32) * (1.0 / 4294967296.0)
+        g = torch.sqrt(-2.0 * torch.log(u1)) * torch.cos((2.0 * np.pi) * u2)
+        f = 100.0 + 37.0 * (u % 64).to(torch.float32)
+        x = 3000.0 * g + 6000.0 * torch.sin((2.0 * np.pi / sr) * f[:, None] * nf[None, :])
+        pcm[u0:u0 + slab] = torch.clamp(torch.round(x), -32768, 32767).to(torch.int16)
+        del h1, h2, u1, u2, g, x
+    return pcm
+
+
+def plan_job(wl, rank, world, scaling, sharding):
+    """Which utterances this rank runs and where they lie in its PCM array: (global ids, offsets, lengths, total samples).
+    weak: the workload's n_utt utterances per rank (ids rank*n_utt ..., fixed per-GPU work); strong: the rank's round-robin
+    share of ONE job of n_utt_total utterances (sharding.shard_layout: rank r owns r, r + world, ...)."""
+    if scaling == "strong":
+        total = wl.get("n_utt_total", wl["n_utt"])
+        lengths = np.full(total, wl["utt_samples"], dtype=np.int64)
+        return sharding.shard_layout(lengths, rank, world)
+    ids = np.arange(wl["n_utt"], dtype=np.int64) + rank * wl["n_utt"]
+    off = np.arange(wl["n_utt"], dtype=np.int64) * wl["utt_samples"]
+    ln = np.full(wl["n_utt"], wl["utt_samples"], dtype=np.int64)
+    return ids, off, ln, int(wl["n_utt"] * wl["utt_samples"])
+
+
+def work_model(wl, width, channels):
+    """SURVEY 8(d) per-frame models: algorithmic flops, the fused path's bytes, and the bytes of a STAGED pipeline (one
+    kernel per reference stage, every intermediate through HBM) for diagnosis."""
+    W, S, nb = wl["W"], wl["S"], wl["nb"]
+    W2 = wl["fft"] or (1 << (W - 1).bit_length())
+    dl = wl["nc"] + (1 if wl.get("c0") else 0)
+    cols = dl if wl["nc"] > 0 else nb
+    lg = W2.bit_length() - 1
+    f_front = W + 2.5 * W2 * lg + 6 * (W2 // 2 + 1) + (2 * nb * dl if wl["nc"] > 0 else 0)
+    f_delta = 6 * cols * wl["dyn"]
+    f_norm = 5 * cols * (1 + wl["dyn"]) if wl.get("norm") else 0
+    staged = 2 * S * channels + 2 * 4 * W2 + 2 * 8 * (W2 // 2 + 1) + 2 * 4 * nb + 2 * 4 * cols * (1 + wl["dyn"]) + \
+        (3 * 4 * width if wl.get("norm") else 0)
+    return dict(flops_front=f_front, flops_delta=f_delta, flops_norm=f_norm, flops=f_front + f_delta + f_norm,
+                staged_bytes=staged, fused_bytes=2 * S * channels + 4 * width)
 
 
 def host_cpu_share():
@@ -122,8 +199,8 @@ def cpu_baseline(orc, wl, pcm_host, window, budget_s=12.0):
     except Exception:
         libpath = None
     cfg = orc.make_config(wl["utt_samples"] + 1000, window_size=wl["W"], shift=wl["S"], num_banks=wl["nb"],
-                          sample_rate=wl["sr"], high_freq=wl["sr"] / 2, ceps_len=wl["nc"], dyn=wl["dyn"],
-                          delta_l1=3, delta_l2=3, fft_mode=1)
+                          sample_rate=wl["sr"], high_freq=wl["sr"] / 2, ceps_len=wl["nc"], want_c0=bool(wl.get("c0")),
+                          norm=wl.get("norm", 0), dyn=wl["dyn"], delta_l1=3, delta_l2=3, fft_mode=1)
     n_avail = pcm_host.shape[0]
 
     def run(n_utt, threads, reps):
@@ -213,6 +290,8 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=100.0,
                     help="run untimed steps until this much wall time of back-to-back GPU work has passed (0: off)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="strong: one job of the workload's n_utt_total utterances sharded round-robin over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true",
                     help="let the delta tail of a step overlap the next step's front end (mfx_batch_overlap); measured "
@@ -253,21 +332,29 @@ def main():
 
     # ---- extractor and batch plan first (they need only the sizes), then the synthetic input
     channels = wl.get("channels", 1)
-    m = pkg.MfccHip(wl["utt_samples"] + 1000, W, S, wl["nb"], wl["sr"], 64.0, wl["sr"] / 2, wl["nc"], False, 22.0,
-                    pkg.NORM_NONE, wl["dyn"], 3, 3, True, device=dev_index, fft_size=wl["fft"], channels=channels)
+    m = pkg.MfccHip(wl["utt_samples"] + 1000, W, S, wl["nb"], wl["sr"], 64.0, wl["sr"] / 2, wl["nc"], bool(wl.get("c0")),
+                    22.0, wl.get("norm", pkg.NORM_NONE), wl["dyn"], 3, 3, True, device=dev_index, fft_size=wl["fft"],
+                    channels=channels)
     m.set_window(window)
-    offsets = np.arange(wl["n_utt"], dtype=np.int64) * wl["utt_samples"]
-    lengths = np.full(wl["n_utt"], wl["utt_samples"], dtype=np.int64)
+    strong = args.scaling == "strong"
+    if strong and "n_utt_total" not in wl:
+        raise SystemExit("bench.py: --scaling strong needs a workload with a job size (C4, T)")
+    utt_ids, offsets, lengths, n_samples_plan = plan_job(wl, rank, world, args.scaling, pkg.sharding)
+    n_utt_rank = int(utt_ids.size)
     if args.overlap:
         m.batch_overlap(True)   # consecutive steps pipeline: tail of step i beside the front end of step i+1
     rows, total_rows = m.batch_plan(offsets, lengths)
     width = m.get_output_data_width()
-    out = torch.empty((total_rows, width), dtype=torch.float32, device=device)
+    out = torch.empty((max(total_rows, 1), width), dtype=torch.float32, device=device)
     # synthetic input resident in HBM (per rank: its own shard of utterances)
-    pcm = synth_pcm_torch(torch, wl["n_utt"], wl["utt_samples"], wl["sr"], seed=rank, device=device)
+    if strong:
+        pcm = synth_pcm_by_index(torch, utt_ids, wl["utt_samples"], wl["sr"], device)
+    else:
+        pcm = synth_pcm_torch(torch, wl["n_utt"], wl["utt_samples"], wl["sr"], seed=rank, device=device)
     if channels == 2:   # interleaved L/R: the right channel is the left one of the neighbouring utterance
         pcm = torch.stack((pcm, torch.roll(pcm, 1, dims=0)), dim=2).contiguous()
     n_samples = pcm.numel() // channels     # per channel
+    assert n_samples >= n_samples_plan
     torch.cuda.synchronize()
 
     def step():
@@ -315,14 +402,20 @@ def main():
     m.profile_enable(False)
 
     frames_rank = int(total_rows)
-    frames_all = frames_rank * world
+    if dist is not None:   # strong scaling: the shards differ by one utterance at most, the total is the sum over ranks
+        t = torch.tensor([frames_rank], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        frames_all = int(t.item())
+    else:
+        frames_all = frames_rank
     ms_per_step = 1e3 * elapsed / args.steps
     value = frames_all / (elapsed / args.steps)
 
     # ---- roofline of the dominant kernel (HIP events on the handle's stream around that kernel)
     bytes_in = 2 * S * channels
-    cols = wl["nc"] if wl["nc"] > 0 else wl["nb"]
+    cols = (wl["nc"] + (1 if wl.get("c0") else 0)) if wl["nc"] > 0 else wl["nb"]
     kname = m.dominant_kernel_name()
+    model = work_model(wl, width, channels)
     # the front-end kernel reads each PCM sample once and writes the static coefficients once;
     # the (small) delta kernel adds the remaining 4*2*cols B/frame of output
     kernel_bytes_per_frame = bytes_in + 4 * cols
@@ -344,14 +437,33 @@ def main():
                 traffic_source = "profiles/traffic_latest.json (%s)" % ent.get("source", "rocprofv3 --pmc passes")
         except Exception:
             traffic = None
+    frames_per_launch = frames_rank / launches_per_step
+    kernel_tflops = model["flops_front"] * frames_per_launch / (avg_kernel_ms * 1e-3) / 1e12 if avg_kernel_ms > 0 else 0.0
+    path_tflops = model["flops"] * frames_rank / (ms_per_step * 1e-3) / 1e12
+    staged_gbs = model["staged_bytes"] * frames_rank / (ms_per_step * 1e-3) / 1e9
     roofline = {
-        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # `achieved` / `peak` / `frac` price the dominant kernel against HBM (the contract's nominal bound for this path).
+        # What the counters say limits it is vector-instruction issue + dependent LDS round trips:
+        # fully fused, the path has ~32 flop/B against a machine balance of ~20 flop/B, so 60 % of the HBM roofline
+        # would need ~100 % of the FP32 vector peak.  Both fractions are reported.
+        "bound": "valu_issue", "bound_nominal": "hbm",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
         "kernel": kname, "kernel_avg_ms": avg_kernel_ms, "kernel_launches_per_step": launches_per_step,
         "algorithmic_bytes_per_frame": kernel_bytes_per_frame,
+        "flops_per_frame": model["flops"], "kernel_flops_per_frame": model["flops_front"],
+        "achieved_tflops": kernel_tflops, "peak_fp32_tflops": FP32_PEAK_TFLOPS,
+        "frac_fp32_peak": kernel_tflops / FP32_PEAK_TFLOPS,
+        "arithmetic_intensity_flop_per_byte": model["flops"] / model["fused_bytes"],
+        "machine_balance_flop_per_byte": FP32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9),
+        "staged_bytes_per_frame": model["staged_bytes"],
+        "staged_pipeline_equivalent": {"achieved": staged_gbs, "frac": staged_gbs / HBM_PEAK_GBS,
+                                       "what": "HBM bytes a one-kernel-per-reference-stage pipeline would move per "
+                                               "frame x this run's frame rate (diagnostic, not traffic)"},
         "whole_path": {"bytes_per_frame": path_bytes_per_frame,
                        "achieved": path_bytes_per_frame * frames_rank / (ms_per_step * 1e-3) / 1e9,
-                       "frac": path_bytes_per_frame * frames_rank / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                       "frac": path_bytes_per_frame * frames_rank / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "achieved_tflops": path_tflops, "frac_fp32_peak": path_tflops / FP32_PEAK_TFLOPS},
     }
 
     result = {
@@ -359,18 +471,22 @@ def main():
                   if args.workload == "C2" else "audio frames/sec (%s)" % wl["desc"],
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "settle_ms": settle_ms, "settle_steps": settle_steps,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %s; per GPU, resident in HBM" % (args.workload, wl["desc"]),
-                   "frames_per_gpu_per_step": frames_rank, "utterances_per_gpu": wl["n_utt"],
-                   "sharding": "independent utterance shards per rank, no collective",
+        "config": {"workload": ("%s: %s; one job over all GPUs, resident in HBM" % (args.workload, wl["desc_strong"])) if strong
+                               else "%s: %s; per GPU, resident in HBM" % (args.workload, wl["desc"]),
+                   "frames_per_step": frames_all, "frames_rank0_per_step": frames_rank, "utterances_rank0": n_utt_rank,
+                   "utterances_total": wl["n_utt_total"] if strong else wl["n_utt"] * world,
+                   "utterance_ids_rank0_head": [int(v) for v in utt_ids[:4]],
+                   "sharding": "round-robin utterance shards (rank r owns r, r + N, ...), no collective" if strong
+                               else "independent utterance shards per rank, no collective",
                    "step_pipelining": "delta tail of step i overlaps front end of step i+1" if args.overlap else "off"},
         "roofline": roofline,
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:   # rank 0 only, the same bounded sample at every N
         orc = G.load_oracle()
-        n_host = min(wl["n_utt"], 512)
+        n_host = min(n_utt_rank, 512)
         pcm_host = pcm[:n_host].cpu().numpy()
         wl_cpu = wl
         if wl["n_utt"] == 1 and wl["utt_samples"] >= 64 * 160000:
@@ -379,6 +495,8 @@ def main():
             seg = 160000
             pcm_host = pcm_host[:, :(pcm_host.shape[1] // seg) * seg].reshape(-1, seg, *pcm_host.shape[2:])[:512]
             wl_cpu = dict(wl, n_utt=pcm_host.shape[0], utt_samples=seg)
+        elif pcm_host.shape[0] != wl["n_utt"]:
+            wl_cpu = dict(wl, n_utt=pcm_host.shape[0])
         if channels == 2:   # the same downmix the kernel applies, done before the timed CPU passes
             pcm_host = ((pcm_host[..., 0].astype(np.int32) + pcm_host[..., 1].astype(np.int32)) >> 1).astype(np.int16)
         result["cpu_baseline"] = cpu_baseline(orc, wl_cpu, pcm_host, window)

@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define MFX_ABI_VERSION 1
+/* 2: mfx_config.batch_norm_stats (default 0 = the reference's block statistics; version 1 libraries took them over all T
+ *    rows) and mfx_config.engine / tail_split, all carved out of reserved[] -- a zeroed reserved[] is still valid. */
+#define MFX_ABI_VERSION 2
 
 typedef enum {
     MFX_OK = 0,
@@ -73,9 +75,21 @@ typedef struct mfx_config {
     int32_t batch_norm_stats;  /* batch entries, norm after dyn: 0 = statistics as the reference computes them for
                                   an utterance it consumes as one block -- over the T - D rows that block delivers,
                                   re-used for the D flush rows (mfcccpu.cpp:377-388,395-407, normalizercpu.cpp:22-27);
-                                  1 = over all T rows of the utterance                                  */
-    int32_t reserved[4];
+                                  1 = over all T rows of the utterance.  Reference parity holds for utterances of at
+                                  most input_buffer_size samples (longer files are several blocks in the reference,
+                                  each with its own statistics: use the streaming entries for those)                  */
+    int32_t engine;            /* MFX_ENGINE_* bits: which of two equivalent kernels serves a configuration (0 = the
+                                  library's choice).  For cross-checks between kernels and A/B measurements; results
+                                  agree to float32 rounding either way                                               */
+    int32_t tail_split;        /* fused batch front ends: the last `tail_split` chunks of every wave of the grid are cut
+                                  into 4-frame pieces so that the launch ends evenly; 0 = default (2), -1 = off        */
+    int32_t reserved[2];
 } mfx_config;
+
+/* mfx_config.engine bits */
+#define MFX_ENGINE_NO_FRONT1024 1 /* 1024-point short-window configurations stay on the generic long-transform kernel  */
+#define MFX_ENGINE_FUSE_DELTA 2   /* 512-point batch path: delta / delta-delta computed by a wave of the front-end kernel
+                                     instead of the separate delta kernel (slower on MI355X)        */
 
 typedef struct mfx_handle mfx_handle;
 

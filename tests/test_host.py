@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(pkg):
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, "declared in include/mfx.h but not exported: %s" % missing
     assert set(declared) == set(pkg.mfcc.EXPORTED_SYMBOLS)
-    assert L.mfx_abi_version() == 1
+    assert L.mfx_abi_version() == 2
 
 
 def test_config_struct_matches_header(pkg, tmp_path):
@@ -424,3 +424,103 @@ def test_front1024_decimation_identity():
         T = (-1j * np.exp(-2j * np.pi * (2 * k + 1) / 1024)) * D
         assert np.allclose((S + T) / 2, X[2 * k + 1], rtol=0, atol=1e-6 * np.abs(X).max())
         assert np.allclose(np.conj(S - T) / 2, X[2 * po + 1], rtol=0, atol=1e-6 * np.abs(X).max())
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py: job planning (weak / strong scaling) and the per-frame work model -- no GPU needed
+# ---------------------------------------------------------------------------------------------
+
+def _import_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_work_model_matches_survey_8d():
+    """SURVEY 8(d): C2 ~ 15 kflop and 476 B per frame (9.1 KB staged), C3 ~ 31 kflop / 372 B, C5 ~ 75 kflop / 2244 B;
+    the reference-defaults workload R carries the normaliser."""
+    B = _import_bench()
+    c2 = B.work_model(B.WORKLOADS["C2"], 39, 1)
+    assert 14000 <= c2["flops"] <= 16000 and c2["fused_bytes"] == 476 and 9000 <= c2["staged_bytes"] <= 9300
+    c3 = B.work_model(B.WORKLOADS["C3"], 13, 1)
+    assert 29000 <= c3["flops"] <= 33000 and c3["fused_bytes"] == 372
+    c5 = B.work_model(B.WORKLOADS["C5"], 120, 2)
+    assert 70000 <= c5["flops"] <= 80000 and c5["fused_bytes"] == 2244
+    r = B.work_model(B.WORKLOADS["R"], 13, 1)
+    assert r["flops_norm"] > 0 and r["flops_delta"] == 0 and r["fused_bytes"] == 320 + 52
+    # intensity above the machine balance: the fused path cannot be HBM-bound at any VALU efficiency below 60 %
+    assert c2["flops"] / c2["fused_bytes"] > B.FP32_PEAK_TFLOPS * 1e12 / (B.HBM_PEAK_GBS * 1e9)
+
+
+def test_bench_plan_job_weak_and_strong(pkg):
+    B = _import_bench()
+    sh = pkg.sharding
+    wl = B.WORKLOADS["T"]
+    for world in (1, 2, 3, 8):
+        seen = []
+        for rank in range(world):
+            ids, off, ln, total = B.plan_job(wl, rank, world, "strong", sh)
+            assert list(ids) == list(range(rank, wl["n_utt_total"], world))          # round-robin, BASELINE configs[3]
+            assert list(off) == [i * wl["utt_samples"] for i in range(ids.size)] and total == ids.size * wl["utt_samples"]
+            seen += list(ids)
+            w_ids, w_off, w_ln, w_total = B.plan_job(wl, rank, world, "weak", sh)
+            assert w_ids.size == wl["n_utt"] and w_total == wl["n_utt"] * wl["utt_samples"]
+        assert sorted(seen) == list(range(wl["n_utt_total"]))
+    assert B.WORKLOADS["C4"]["n_utt_total"] == 100000 and B.WORKLOADS["C4"]["n_utt"] * 8 == 100000
+
+
+def test_bench_synth_by_index_is_a_function_of_the_utterance_index():
+    """Strong scaling computes ONE job at every N: an utterance's PCM depends on its global index only (CPU tensors here)."""
+    import torch
+    B = _import_bench()
+    a = B.synth_pcm_by_index(torch, [0, 1, 2, 3, 4, 5], 4000, 16000.0, "cpu")
+    b = B.synth_pcm_by_index(torch, [4, 1], 4000, 16000.0, "cpu")
+    assert torch.equal(a[4], b[0]) and torch.equal(a[1], b[1]) and not torch.equal(a[0], a[1])
+    x = a.to(torch.float32)
+    assert 3000 < float(x.std()) < 6500 and abs(float(x.mean())) < 200          # 3000 N(0,1) + 6000 sin(...)
+
+
+_STRONG_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import importlib.util
+import __graft_entry__ as G
+pkg = G.load_package()
+spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(sys.argv[1], "bench.py"))
+B = importlib.util.module_from_spec(spec); spec.loader.exec_module(B)
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+wl = B.WORKLOADS["T"]
+ids, off, ln, total = B.plan_job(wl, rank, world, "strong", pkg.sharding)
+owned = torch.zeros(wl["n_utt_total"], dtype=torch.int64); owned[torch.from_numpy(ids)] = 1
+dist.all_reduce(owned)
+assert bool((owned == 1).all())                                   # a partition of the one job
+assert list(ids) == list(range(rank, wl["n_utt_total"], world))   # and the round-robin one
+frames = int(pkg.sharding.frames_of(ln, wl["W"], wl["S"]).sum())
+tot = pkg.sharding.gather_counts(frames, dist)
+assert tot == wl["n_utt_total"] * ((wl["utt_samples"] - (wl["W"] - wl["S"])) // wl["S"]), tot
+pcm = B.synth_pcm_by_index(torch, ids, wl["utt_samples"], wl["sr"], "cpu")
+# utterance 2 (rank 0 at world 2) and utterance 3 (rank 1): the same bits as a single-rank run would generate
+ref = B.synth_pcm_by_index(torch, [2 + rank], wl["utt_samples"], wl["sr"], "cpu")
+assert torch.equal(pcm[1], ref[0])
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_rank_gloo_strong_scaling_job(tmp_path):
+    """bench.py --scaling strong, world_size 2 on gloo: the two ranks' utterance sets are the round-robin partition of the
+    one job, the frame total is the job's, and each rank generates exactly the PCM a one-rank run generates."""
+    script = tmp_path / "worker_strong.py"
+    script.write_text(_STRONG_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29537", str(script), ROOT],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert r.stdout.count("ok") >= 2

@@ -16,13 +16,13 @@ pytestmark = pytest.mark.gpu
 
 
 def make_pair(pkg, orc, ibs, W=400, S=160, nb=40, sr=16000.0, low=64.0, high=None, nc=13, c0=False, lift=22.0,
-              norm=0, dyn=2, l1=3, l2=3, nad=True, fft_size=0, channels=1, bug_compat=True, window=None):
+              norm=0, dyn=2, l1=3, l2=3, nad=True, fft_size=0, channels=1, bug_compat=True, window=None, engine=0):
     """The HIP extractor and the oracle extractor with identical parameters."""
     high = sr / 2 if high is None else high
     if window is None:
         window = pkg.reference_window(W)
     m = pkg.MfccHip(ibs, W, S, nb, sr, low, high, nc, c0, lift, norm, dyn, l1, l2, nad, device=0, fft_size=fft_size,
-                    channels=channels, bug_compat=bug_compat)
+                    channels=channels, bug_compat=bug_compat, engine=engine)
     m.set_window(window)
     if fft_size:
         # the oracle (like the reference) ties the FFT length to the window: express "W taps zero
@@ -451,7 +451,7 @@ _F1024 = [
 def test_front1024_configurations(pkg, orc, W, S, nb, nc, c0, dyn, alpha):
     """k_front1024 (1024 points, <= 80 filters, <= 16 columns; windows longer than 512 samples on aligned frames only): ragged utterances at odd and even
     offsets through the batch entry against the oracle fed each utterance alone (its 1024-tap window loses the last few
-    frames: common prefix), and the same batch through k_front_reg (MFX_NO_FRONT1024=1: a different factorisation of
+    frames: common prefix), and the same batch through k_front_reg (mfx_config.engine = MFX_ENGINE_NO_FRONT1024: a different factorisation of
     the same transform) within the same tolerance."""
     import os
     rng = np.random.default_rng(W * 7 + S)
@@ -476,11 +476,7 @@ def test_front1024_configurations(pkg, orc, W, S, nb, nc, c0, dyn, alpha):
     assert m.dominant_kernel_name() == ("k_front1024" if (W <= 512 or S % 2 == 0) else "k_front_reg")
     got = m.batch_run_host(pcm)
     assert total == sum(frames) and got.shape[0] == total
-    os.environ["MFX_NO_FRONT1024"] = "1"
-    try:
-        m2, _, _ = make_pair(pkg, orc, max(lens) + 2000, **kw)
-    finally:
-        del os.environ["MFX_NO_FRONT1024"]
+    m2, _, _ = make_pair(pkg, orc, max(lens) + 2000, engine=pkg.mfcc.ENGINE_NO_FRONT1024, **kw)
     assert m2.dominant_kernel_name() == "k_front_reg"
     if alpha != 1.0:
         m2.set_alpha(alpha)
@@ -880,10 +876,17 @@ def test_bench_two_rank_launch_path(tmp_path):
     assert len(lines) == 1, r.stdout[-2000:]           # rank 0 prints ONE line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
-    assert d["config"]["frames_per_gpu_per_step"] == 8 * 98
+    assert d["config"]["frames_rank0_per_step"] == 8 * 98 and d["config"]["frames_per_step"] == 2 * 8 * 98
     # whole-job value = frames of all ranks / max-over-ranks step time
     assert abs(d["value"] - 2 * 8 * 98 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert "roofline" in d and "cpu_baseline" not in d
+    # the line says what bounds the kernel and carries SURVEY 8(d)'s compute-side model next to the HBM fraction
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "flops_per_frame", "achieved_tflops",
+              "frac_fp32_peak", "staged_bytes_per_frame", "staged_pipeline_equivalent", "whole_path"):
+        assert k in rf, k
+    assert rf["bound"] == "valu_issue" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert 14000 <= rf["flops_per_frame"] <= 16000 and 9000 <= rf["staged_bytes_per_frame"] <= 9300
 
 
 def test_bench_self_launch_two_ranks():
@@ -905,6 +908,44 @@ def test_bench_self_launch_two_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["settle_ms"] >= 5
     assert abs(d["value"] - 2 * 8 * 98 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+def test_bench_self_launch_two_ranks_strong_scaling():
+    """`bench.py --gpus 2 --scaling strong`: ONE job (workload T: 13 utterances) sharded round-robin over the two ranks
+    (7 + 6 utterances), total frames / max-over-ranks time, `scaling: "strong"`, and the CPU baseline on rank 0 at N > 1."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MFX_BENCH_DEVICE="0", MFX_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--settle-ms", "5", "--workload", "T", "--scaling", "strong"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    c = d["config"]
+    assert c["utterances_total"] == 13 and c["utterances_rank0"] == 7 and c["utterance_ids_rank0_head"] == [0, 2, 4, 6]
+    assert c["frames_per_step"] == 13 * 98 and c["frames_rank0_per_step"] == 7 * 98
+    assert abs(d["value"] - 13 * 98 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+
+
+def test_bench_reference_defaults_workload_runs_the_normaliser():
+    """`--workload R` = the reference main()'s defaults (15 banks, 12 + c0, CVN): a bench line whose step contains the
+    normaliser kernels (steps kept tiny here; the timed evidence lives in profiles/)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--settle-ms", "5",
+                        "--workload", "R", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["config"]["frames_per_step"] == 998000 and "CVN" in d["config"]["workload"]
+    assert d["roofline"]["algorithmic_bytes_per_frame"] == 320 + 52
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1082,12 +1123,10 @@ def test_batch_overlap_mode_is_bit_identical(pkg, orc):
 # ---------------------------------------------------------------------------------------------
 
 def _fuse_pair(pkg, orc, monkeypatch, **kw):
-    """Two extractors with identical parameters: fused delta stage on (opt-in, MFX_FUSE_DELTA=1) and off."""
-    monkeypatch.setenv("MFX_FUSE_DELTA", "1")
-    m_f, cfg, w = make_pair(pkg, orc, 200000, **kw)
-    monkeypatch.setenv("MFX_FUSE_DELTA", "0")
+    """Two extractors with identical parameters: fused delta stage on (opt-in, mfx_config.engine = MFX_ENGINE_FUSE_DELTA)
+    and off."""
+    m_f, cfg, w = make_pair(pkg, orc, 200000, engine=pkg.mfcc.ENGINE_FUSE_DELTA, **kw)
     m_u, _, _ = make_pair(pkg, orc, 200000, **kw)
-    monkeypatch.delenv("MFX_FUSE_DELTA")
     return m_f, m_u, cfg, w
 
 

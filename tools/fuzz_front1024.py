@@ -1,5 +1,5 @@
 """Dev aid: random 1024-point short-window configurations through k_front1024 and through k_front_reg
-(MFX_NO_FRONT1024=1), ragged utterances at random offsets; prints the worst relative differences."""
+(mfx_config.engine = MFX_ENGINE_NO_FRONT1024), ragged utterances at random offsets; prints the worst relative differences."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,8 +33,7 @@ for case in range(n_cases):
     pcm = (4000.0 * rng.standard_normal(pos)).round().clip(-32768, 32767).astype(np.int16)
     outs = []
     for no in ("0", "1"):
-        os.environ["MFX_NO_FRONT1024"] = no
-        m = pkg.MfccHip(max(lens) + 2000, W, S, nb, sr, 64.0, sr / 2, nc, c0, 22.0, 0, dyn, 2, 2, True, fft_size=1024)
+        m = pkg.MfccHip(max(lens) + 2000, W, S, nb, sr, 64.0, sr / 2, nc, c0, 22.0, 0, dyn, 2, 2, True, fft_size=1024, engine=int(no))
         m.set_window(pkg.reference_window(W))
         if alpha != 1.0:
             m.set_alpha(alpha)
