@@ -64,7 +64,10 @@ TOL_MAX = 1e-4   # max |a-b| / max |b|
 TOL_L2 = 1e-5    # ||a-b||_2 / ||b||_2
 
 
-def assert_close(got, want, what="", tol_max=TOL_MAX, tol_l2=TOL_L2, groups=None):
+def assert_close(got, want, what="", tol_max=TOL_MAX, tol_l2=TOL_L2, groups=None, scale_floor=0.0):
+    """scale_floor: lower bound of the signal scale the errors are measured against -- for outputs that are themselves
+    rounding noise (an all-silent utterance: every log energy is log(1e-30) = -69.08 and the DCT of a constant vector
+    cancels to ~1e-5), where the scale of the DCT's INPUT is the meaningful yardstick."""
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
     assert got.shape == want.shape, "%s: shape %s vs %s" % (what, got.shape, want.shape)
@@ -76,9 +79,9 @@ def assert_close(got, want, what="", tol_max=TOL_MAX, tol_l2=TOL_L2, groups=None
     w = cols // g
     for i in range(g):
         a, b = got[:, i * w:(i + 1) * w], want[:, i * w:(i + 1) * w]
-        scale = max(np.abs(b).max(), 1e-30)
+        scale = max(np.abs(b).max(), 1e-30, scale_floor)
         emax = np.abs(a - b).max() / scale
-        el2 = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+        el2 = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30, scale_floor * np.sqrt(b.size))
         assert emax <= tol_max, "%s group %d: max err / max|ref| = %.3g > %.3g" % (what, i, emax, tol_max)
         assert el2 <= tol_l2, "%s group %d: rel L2 = %.3g > %.3g" % (what, i, el2, tol_l2)
 
