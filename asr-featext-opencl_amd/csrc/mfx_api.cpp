@@ -84,6 +84,10 @@ struct mfx_handle {
     bool wplan_ok = false;
     DevBuf<float> d_mel64_w, d_dct_b;
     DevBuf<int32_t> d_mel64_start, d_mel64_fid;
+    DevBuf<float> d_mel32_w;                         // k_front2048: the 32-lane plan
+    DevBuf<int32_t> d_mel32_start, d_mel32_fid;
+    MelWavePlan wplan32;
+    bool fast2048 = false, wplan32_ok = false;
     int dct_tiles = 0, dct_ksteps = 0;
     int dct_stride = 0, nb_pad = 0;
     bool fused_ok = false;
@@ -240,6 +244,20 @@ int refresh_mel(mfx_handle *h)
             h->wplan_ok = true;
         }
     }
+    h->wplan32_ok = false;
+    if (h->fast2048) { // k_front2048 walks the filters on the 32 lanes of each of a wave's two frames
+        if (build_mel_wave_plan(t, h->nb, h->W2, /*max_read_bin=*/1039, h->wplan32, /*lanes=*/32)) {
+            HIP_TRY(h, upload(h->d_mel32_w, h->wplan32.w));
+            HIP_TRY(h, upload(h->d_mel32_start, h->wplan32.start));
+            HIP_TRY(h, upload(h->d_mel32_fid, h->wplan32.fid));
+            FrontParams probe;
+            std::memset(&probe, 0, sizeof(probe));
+            probe.num_banks = h->nb;
+            probe.mel32_rounds = h->wplan32.rounds;
+            probe.mel32_row_stride = h->wplan32.row_stride;
+            h->wplan32_ok = front2048_lds_bytes(probe) <= 160 * 1024;
+        }
+    }
     h->table_alpha = h->alpha;
     return MFX_OK;
 }
@@ -285,6 +303,12 @@ void fill_front(const mfx_handle *h, FrontParams &p)
     p.mel64_rounds = h->wplan_ok ? h->wplan.rounds : 0;
     p.mel64_row_stride = h->wplan_ok ? h->wplan.row_stride : 0;
     for (int i = 0; i < 8; ++i) p.mel64_L[i] = h->wplan.L[i];
+    p.mel32_w = h->d_mel32_w.p;
+    p.mel32_start = h->d_mel32_start.p;
+    p.mel32_fid = h->d_mel32_fid.p;
+    p.mel32_rounds = h->wplan32_ok ? h->wplan32.rounds : 0;
+    p.mel32_row_stride = h->wplan32_ok ? h->wplan32.row_stride : 0;
+    for (int i = 0; i < 8; ++i) p.mel32_L[i] = h->wplan32.L[i];
     p.dct_b = h->ceps > 0 ? h->d_dct_b.p : nullptr;
     p.dct_tiles = h->dct_tiles;
     p.dct_ksteps = h->dct_ksteps;
@@ -417,6 +441,9 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_mel64_start.release();
     h->d_mel64_fid.release();
     h->d_dct_b.release();
+    h->d_mel32_w.release();
+    h->d_mel32_start.release();
+    h->d_mel32_fid.release();
     h->d_dct_t.release();
     h->d_mel_lane_start.release();
     h->d_mel_lane_fid.release();
@@ -523,6 +550,7 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
     }
     h->spec_pitch = ((h->W2 / 2 + 1) + 3) & ~3;
     h->fast512 = front512_supported(h->W2, h->W, h->nb, h->cols, h->channels);
+    h->fast2048 = !(h->cfg.engine & MFX_ENGINE_NO_FRONT2048) && front2048_supported(h->W2, h->W, h->nb, h->cols, h->channels);
     h->fast1024 = !(h->cfg.engine & MFX_ENGINE_NO_FRONT1024) &&
                   front1024_supported(h->W2, h->W, h->nb, h->cols, h->channels, h->ceps);
     {
@@ -722,6 +750,7 @@ extern "C" int mfx_profile_read(mfx_handle *h, int32_t *launches, double *kernel
 extern "C" const char *mfx_dominant_kernel_name(const mfx_handle *h)
 {
     if (!h) return "";
+    if (h->fast2048 && h->wplan32_ok && (h->channels == 2 || ((h->S % 2) == 0 && (h->W % 2) == 0 && h->batch_aligned))) return "k_front2048";
     return h->fast512 ? "k_front512" : (h->fast1024 && h->fused_ok && (h->W <= 512 || h->batch_aligned)) ? "k_front1024" : h->W2 >= 1024 ? "k_front_reg" : "k_front_wave"; // names as rocprofv3 prints them
 }
 
@@ -1561,7 +1590,9 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
     const bool fused1024 = h->fast1024 && h->fused_ok && (h->W <= 512 || h->batch_aligned); // (long windows: aligned frames only)
     // (up to 2048 points the fused form saves the spectrum's round trip through HBM -- 8 KB per frame at 2048
     // points; at 4096 points the tables + per-wave buffers no longer leave enough waves per CU)
-    const bool fusedgen = !fused512 && !fused1024 && h->W2 <= 2048 && (h->W2 < 1024 || h->wplan_ok) &&
+    // (2048 points, window <= 1152 samples: two frames per wave; mono needs aligned sample pairs)
+    const bool fused2048 = h->fast2048 && h->wplan32_ok && (h->channels == 2 || p.pair_ok);
+    const bool fusedgen = !fused512 && !fused1024 && !fused2048 && h->W2 <= 2048 && (h->W2 < 1024 || h->wplan_ok) &&
                           front_wave_lds_bytes(p, true) <= 160 * 1024;
     // With deltas on, the front end writes its statics as compact 64-byte rows into a scratch buffer
     // and the delta kernel emits whole [static | d | dd] rows: every HBM write is then a full line
@@ -1571,7 +1602,7 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
     // event, so the memory-bound tail of batch i shares the GPU with the compute-bound front end of
     // batch i+1; the statics scratch is double buffered and the front end of batch i+2 waits for tail i.
     const int sb = (h->overlap && whole) ? (int)(h->batch_seq & 1) : 0;
-    const bool via_scratch = ((fused512 && p.dct_mode == 1) || fused1024 || fusedgen) && h->l1 > 0 && h->cols <= 16 && !norm_before &&
+    const bool via_scratch = ((fused512 && p.dct_mode == 1) || fused1024 || fused2048 || fusedgen) && h->l1 > 0 && h->cols <= 16 && !norm_before &&
                              h->d_static16[sb].n >= (size_t)h->total_rows * 16;
     // Fused delta stage: the 512-point kernel's last wave per block turns the statics into whole output
     // rows while the other 15 produce them; no separate delta launch.
@@ -1610,6 +1641,9 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
     } else if (fused1024) {
         ProfScope ps(h);
         HIP_TRY(h, launch_front1024(p, h->batch_aligned, h->nm16, h->stream));
+    } else if (fused2048) {
+        ProfScope ps(h);
+        HIP_TRY(h, launch_front2048(p, h->num_cus, h->stream));
     } else if (fusedgen) {
         ProfScope ps(h);
         HIP_TRY(h, launch_front_generic(p, /*fused=*/true, h->stream));

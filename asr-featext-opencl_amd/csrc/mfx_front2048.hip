@@ -1,0 +1,474 @@
+// mfx_front2048.hip -- k_front2048: the fused front end for 2048-point transforms of a short window
+// (BASELINE configs[4]: 44.1 kHz, 25 ms = 1102 samples zero padded to 2048, stereo or mono, 128 mel, 40 MFCC).
+//
+// Replaces, for that shape, the reference stages segmenter.cl kernelSegmentWindow + AppleFFT (one LDS kernel up to
+// 2048 points, AppleFFT/fft_kernelstring.cpp:165-177) + mfcc.cl kernelTranspose / kernelFilter + the DCT slot
+// (mfccopencl.cpp:315-358); numerics follow mfcccpu.cpp:192-232.
+//
+// Shape of the work (round 3; k_front_reg ran one WAVE per frame with three Stockham passes and ~11 dependent LDS round
+// trips per frame -- DESIGN.md section 7 found it bound by exactly that):
+//   * TWO frames per wave, 32 lanes per frame.  The real 2048-point DFT of a frame is the complex 1024-point DFT of
+//     z[n] = x[2n] + i x[2n+1] plus a real split; 1024 = 32 x 32:
+//        lane n1 : Y[n1][k2] = sum_n2 z[n1 + 32 n2] W_32^(n2 k2)    32-point DFT in registers (only n2 < 18 carry taps:
+//                                                                    the zero inputs fold away at compile time)
+//        twiddle : Y *= W_1024^(n1 k2)                               table in LDS, two values per 16-byte read
+//        LDS     : 32 x 32 transposition, real parts then imaginary parts through ONE 4 KB plane per frame
+//                  (16-byte writes, 4-byte reads, XOR-swizzled: both conflict free)
+//        lane k2 : Z[k2 + 32 k1] = sum_n1 Y[n1][k2] W_32^(n1 k1)    second 32-point DFT in registers
+//     i.e. two passes and ONE transposition where the 16.16.4 factorisation had three passes and three.
+//   * real split over the bin pairs (k, 1024 - k): lane l holds k = l + 32 k1 (k1 < 16) in its lower registers; the
+//     partner Z[1024 - k] is register 31 - k1 of lane 32 - l of the same frame: 32 ds_bpermute (no LDS memory), all in
+//     flight at once.  |S + T| and |S - T| are the two magnitudes (as k_front512).
+//   * magnitudes back into the frame's plane, mel filters walked on the frame's 32 lanes (rounds of 32 filters, longest
+//     first, one ascending chain of multiply-adds per filter = the reference's order, mfcccpu.cpp:206-217), log, and the
+//     DCT-II + lifter on the matrix pipe once per 4 frames (v_mfma_f32_16x16x4_f32: an exact k-ordered fmaf chain).
+//   * the samples of the NEXT two frames are requested right after the current ones are converted (registers just
+//     freed), chunks are drawn from a block-local LDS counter, PCM goes through buffer loads with a per-chunk descriptor
+//     (hardware range check).
+// A frame costs ~5 dependent LDS round trips per PAIR of frames, and with 12 waves per CU 24 frames are in flight per CU
+// (k_front_reg: 10).
+#include "mfx_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include "mfx_dev.h"
+
+namespace mfx {
+
+namespace {
+
+constexpr int kW2048 = 12;        // waves per block; one block per CU (LDS: ~33 KB of tables + 10.5 KB per wave)
+constexpr int kPlane = 1040;      // floats per frame plane: 1024 transposition words / 1025 magnitudes + finite slack
+constexpr int kRows2048 = 18;     // rows of 32 sample pairs that can carry window taps: W <= 1152
+
+// cos / sin of 2 pi e / 32
+__host__ __device__ constexpr float c32(int e)
+{
+    constexpr float q[9] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                            0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
+                            0.19509032201612826785f, 0.0f};
+    e &= 31;
+    return e <= 8 ? q[e] : e <= 16 ? -q[16 - e] : e <= 24 ? -q[e - 16] : q[32 - e];
+}
+__host__ __device__ constexpr float s32(int e) { return c32(e - 8); }
+
+// a * W_32^E, constants as literals ("x * K + y * K2": v_mul + v_fmac with literal operands, full issue rate)
+template <int E>
+__device__ __forceinline__ float2 mul_w32(float2 a)
+{
+    constexpr int e = E & 31;
+    if (e == 0) return a;
+    if (e == 8) return make_float2(a.y, -a.x);
+    if (e == 16) return make_float2(-a.x, -a.y);
+    if (e == 24) return make_float2(-a.y, a.x);
+    constexpr float c = c32(e), s = s32(e), ns = -s32(e);
+    return make_float2(a.x * c + a.y * s, a.y * c + a.x * ns); // (c - i s)(x + i y)
+}
+
+// 32-point forward DFT in registers, natural order in and out: n = 8 a + b, k = c + 4 d,
+//   X[c + 4 d] = sum_b W_8^(b d) [ W_32^(b c) sum_a x[8 a + b] W_4^(a c) ].
+// Inputs that are compile-time zeros fold away after inlining (pass 1: only x[0..17] carry data).
+__device__ __forceinline__ void fft32(float2 (&x)[32])
+{
+    float2 y[32]; // y[8 c + b]
+#pragma unroll
+    for (int b = 0; b < 8; ++b) dft4(x[b], x[8 + b], x[16 + b], x[24 + b], y[b], y[8 + b], y[16 + b], y[24 + b]);
+#define MFX_TW32(c, b) y[8 * c + b] = mul_w32<c * b>(y[8 * c + b])
+    MFX_TW32(1, 1); MFX_TW32(1, 2); MFX_TW32(1, 3); MFX_TW32(1, 4); MFX_TW32(1, 5); MFX_TW32(1, 6); MFX_TW32(1, 7);
+    MFX_TW32(2, 1); MFX_TW32(2, 2); MFX_TW32(2, 3); MFX_TW32(2, 4); MFX_TW32(2, 5); MFX_TW32(2, 6); MFX_TW32(2, 7);
+    MFX_TW32(3, 1); MFX_TW32(3, 2); MFX_TW32(3, 3); MFX_TW32(3, 4); MFX_TW32(3, 5); MFX_TW32(3, 6); MFX_TW32(3, 7);
+#undef MFX_TW32
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float2 t[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) t[b] = y[8 * c + b];
+        fft8(t);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) x[c + 4 * d] = t[d];
+    }
+}
+
+// LDS floats: shared tables, then per wave two planes and the log mel energies of 4 frames
+__host__ __device__ inline size_t front2048_table_floats(int rounds, int row_stride)
+{
+    return 2 * (size_t)(32 * kRows2048)      // window pairs
+           + 4 * (size_t)(16 * 32)            // pass twiddles, two per 16-byte word
+           + 4 * (size_t)(8 * 32) + 4         // split twiddles, two per 16-byte word; + the self-paired bin 512
+           + (size_t)32 * row_stride          // mel weight rows
+           + (size_t)64 * rounds;             // starts + filter ids
+}
+
+template <bool STEREO>
+__global__ void __launch_bounds__(kW2048 * 64, 3) k_front2048(FrontParams p)
+{
+    constexpr int M = 1024, NR = kRows2048;
+    constexpr int NWORD = STEREO ? 2 * NR : NR; // raw 32-bit words per lane and frame
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int l = lane & 31, half = lane >> 5;
+    const int nb = p.num_banks;
+    const int RS = p.mel32_row_stride, rounds = p.mel32_rounds;
+    const int nbp = lm_stride(nb);
+
+    float2 *s_win = (float2 *)smem;                                // [18][32] (w[2n], w[2n+1]) * 0.5 / W2
+    float4 *s_tw = (float4 *)(s_win + 32 * NR);                    // [16][32] (W_1024^(n1 2j), W_1024^(n1 (2j+1)))
+    float4 *s_cs = s_tw + 16 * 32;                                 // [8][32]  (cs[l + 64 j], cs[l + 64 j + 32]), cs[k] = -i W_2048^k
+    float2 *s_cs512 = (float2 *)(s_cs + 8 * 32);                   // cs[512] (+ pad)
+    float *s_mw = (float *)(s_cs512 + 2);                          // [32][RS]
+    int *s_mst = (int *)(s_mw + 32 * RS);                          // [rounds][32]
+    int *s_mfid = s_mst + 32 * rounds;                             // [rounds][32]
+    float *s_wave = (float *)(s_mfid + 32 * rounds) + wave * (2 * kPlane + 4 * nbp);
+    float *plane = s_wave + half * kPlane;                         // this frame's plane
+    float *lm = s_wave + 2 * kPlane;                               // [4][nbp]
+    int *s_ctr = (int *)((float *)(s_mfid + 32 * rounds) + kW2048 * (2 * kPlane + 4 * nbp));
+    if (tid == 0) *s_ctr = 0;
+
+    const float scale = p.scale; // 0.5 / W2 (a power of two: exact)
+    for (int i = tid; i < 32 * NR; i += blockDim.x) {
+        const float2 wv = 2 * i < p.fft_size ? ((const float2 *)p.window)[i] : make_float2(0.f, 0.f); // (zero padded to W2)
+        s_win[i] = make_float2(wv.x * scale, wv.y * scale);
+    }
+    for (int i = tid; i < 16 * 32; i += blockDim.x) {
+        const int j = i >> 5, n1 = i & 31;
+        const float2 a = ((const float2 *)p.twid_half)[(n1 * 2 * j) & (M - 1)];
+        const float2 b = ((const float2 *)p.twid_half)[(n1 * (2 * j + 1)) & (M - 1)];
+        s_tw[i] = make_float4(a.x, a.y, b.x, b.y);
+    }
+    for (int i = tid; i < 8 * 32; i += blockDim.x) {
+        const int j = i >> 5, ll = i & 31;
+        const float2 a = ((const float2 *)p.twid_split)[ll + 64 * j];
+        const float2 b = ((const float2 *)p.twid_split)[ll + 64 * j + 32];
+        s_cs[i] = make_float4(a.x, a.y, b.x, b.y);
+    }
+    if (tid < 2) s_cs512[tid] = tid == 0 ? ((const float2 *)p.twid_split)[512] : make_float2(0.f, 0.f);
+    for (int i = tid; i < 32 * RS; i += blockDim.x) s_mw[i] = p.mel32_w[i];
+    for (int i = tid; i < 32 * rounds; i += blockDim.x) {
+        s_mst[i] = p.mel32_start[i];
+        s_mfid[i] = p.mel32_fid[i];
+    }
+    for (int i = lane; i < 2 * kPlane + 4 * nbp; i += 64) s_wave[i] = 0.f; // (words the walk may read but nothing writes)
+    __syncthreads();
+
+    // ---- per-lane constants
+    // transposition plane, value (n1, k2) at word n1 * 32 + (((k2 >> 2) ^ n1) & 7) * 4 + (k2 & 3):
+    //   lane n1 writes its 8 chunks of 4 consecutive k2 as 16-byte words (8 consecutive lanes: 8 distinct bank quads),
+    //   lane k2 reads word (n1, k2) for n1 = 0..31 (32 lanes: a permutation of one 32-word row)
+    int wr_off[8], rd_off[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        wr_off[j] = l * 32 + ((j ^ l) & 7) * 4;
+        rd_off[j] = j * 32 + ((((l >> 2) ^ j) & 7) * 4) + (l & 3); // row n1 = j + 8 m: + 256 m words
+    }
+    const int part_addr = (((32 - l) & 31) | (lane & 32)) * 4; // ds_bpermute: partner lane of the real split
+    const bool lane0 = l == 0;
+
+    // ---- chunk walk: block b owns chunks b, b + B, ...; its waves draw from that list through a counter in LDS
+    struct ChunkCtx {
+        int64_t out_row;
+        int n_live;
+        __amdgpu_buffer_rsrc_t rsrc;
+    };
+    auto make_ctx = [&](int c) -> ChunkCtx {
+        ChunkCtx x;
+        const bool valid = c < p.n_chunks;
+        const Chunk *chp = p.chunks + (valid ? c : 0);
+        const int64_t pcm_off = chp->pcm_off;
+        x.out_row = chp->out_row;
+        const int n_frames = valid ? chp->n_frames : 0;
+        const int64_t rows_left = p.row_limit - x.out_row;
+        x.n_live = (int)(rows_left < n_frames ? (rows_left < 0 ? 0 : rows_left) : n_frames);
+        // buffer descriptor over [chunk start, end of PCM): out-of-range lanes read 0 (whole 32-bit words: see k_front512)
+        const int64_t el0 = pcm_off * (STEREO ? 2 : 1);
+        int64_t bytes_left = valid ? (((p.pcm_total - el0) * 2 + 3) & ~(int64_t)3) : 0;
+        if (bytes_left > 0xfffffff0ll) bytes_left = 0xfffffff0ll;
+        if (bytes_left < 0) bytes_left = 0;
+        const uintptr_t bp = (uintptr_t)(p.pcm + el0);
+        const uint32_t bp_lo = __builtin_amdgcn_readfirstlane((uint32_t)bp);
+        const uint32_t bp_hi = __builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32));
+        const uint32_t nbytes = __builtin_amdgcn_readfirstlane((uint32_t)bytes_left);
+        x.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(((uintptr_t)bp_hi << 32) | bp_lo), 0, nbytes, 0x00020000);
+        return x;
+    };
+    auto draw = [&]() -> int {
+        int k = 0;
+        if (lane == 0) k = __hip_atomic_fetch_add(s_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        k = __builtin_amdgcn_readfirstlane(k);
+        const long long cc = (long long)blockIdx.x + (long long)k * gridDim.x;
+        return cc < p.n_chunks ? (int)cc : p.n_chunks;
+    };
+    // raw words of (frame f, this lane): sample pair n = l + 32 j at byte (f S + 2 n) * (STEREO ? 4 : 2)
+    uint32_t raw[NWORD];
+    auto issue = [&](const ChunkCtx &x, int f) {
+        const int voff = (f * p.shift + 2 * l) * (STEREO ? 4 : 2);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            if (STEREO) {
+                raw[2 * j] = __builtin_amdgcn_raw_buffer_load_b32(x.rsrc, voff + 256 * j, 0, 0);
+                raw[2 * j + 1] = __builtin_amdgcn_raw_buffer_load_b32(x.rsrc, voff + 256 * j + 4, 0, 0);
+            } else {
+                raw[j] = __builtin_amdgcn_raw_buffer_load_b32(x.rsrc, voff + 128 * j, 0, 0);
+            }
+        }
+    };
+
+    int c_cur = draw(), c_nxt = draw();
+    ChunkCtx ccur = make_ctx(c_cur), cnxt = make_ctx(c_nxt);
+    issue(ccur, half);
+    while (c_cur < p.n_chunks) {
+        const int64_t out_row = ccur.out_row;
+        const int n_live = ccur.n_live;
+        for (int f0 = 0; f0 < n_live; f0 += 2) {
+            const int f = f0 + half;
+            const bool last = f0 + 2 >= n_live;
+            // ---- framing + window: z[n2] = (w[2n] x[2n], w[2n+1] x[2n+1]), n = l + 32 n2
+            float2 z[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                if (j >= NR) {
+                    z[j] = make_float2(0.f, 0.f);
+                    continue;
+                }
+                float x0, x1;
+                if (STEREO) { // one 32-bit word per sample (L | R << 16); mono = (L + R) >> 1 as the reference driver's caller
+                    const uint32_t d0 = raw[2 * j], d1 = raw[2 * j + 1];
+                    x0 = (float)(((int)(short)(d0 & 0xffffu) + ((int)d0 >> 16)) >> 1);
+                    x1 = (float)(((int)(short)(d1 & 0xffffu) + ((int)d1 >> 16)) >> 1);
+                } else {
+                    const uint32_t d = raw[j];
+                    x0 = (float)(int)(short)(d & 0xffffu);
+                    x1 = (float)((int)d >> 16);
+                }
+                const float2 w = s_win[l + 32 * j];
+                z[j] = make_float2(w.x * x0, w.y * x1);
+            }
+            // the next two frames of this chunk or, from its last iteration, the first two of the next chunk: requested
+            // now, unconditionally, into the registers just consumed
+            if (last)
+                issue(cnxt, half);
+            else
+                issue(ccur, f + 2);
+
+            // ---- pass 1 + inter-pass twiddle
+            fft32(z);
+            {
+                float4 tq[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) tq[j] = lds_read_b128(s_tw + j * 32 + l);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (j > 0) z[2 * j] = cmul(z[2 * j], make_float2(tq[j].x, tq[j].y));
+                    z[2 * j + 1] = cmul(z[2 * j + 1], make_float2(tq[j].z, tq[j].w));
+                }
+            }
+            // ---- 32 x 32 transposition through the frame's plane: real parts, then imaginary parts.  The LDS executes a
+            // wave's instructions in order, so the imaginary parts' writes need not wait for the real parts' reads.
+            float zr[32], zi[32];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *(float4 *)(plane + wr_off[j]) = make_float4(z[4 * j].x, z[4 * j + 1].x, z[4 * j + 2].x, z[4 * j + 3].x);
+            wave_sync();
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) zr[n1] = plane[rd_off[n1 & 7] + 256 * (n1 >> 3)];
+            wave_sync();
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *(float4 *)(plane + wr_off[j]) = make_float4(z[4 * j].y, z[4 * j + 1].y, z[4 * j + 2].y, z[4 * j + 3].y);
+            wave_sync();
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) zi[n1] = plane[rd_off[n1 & 7] + 256 * (n1 >> 3)];
+            wave_sync();
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) z[n1] = make_float2(zr[n1], zi[n1]);
+
+            // ---- pass 2: lane k2 = l now holds Z[l + 32 k1] in z[k1]
+            fft32(z);
+
+            // ---- real split over the pairs (k, 1024 - k), k = l + 32 k1, k1 < 16.  Z[1024 - k] is register 31 - k1 of
+            // lane 32 - l; lane 0 pairs with itself: register 32 - k1 (and Z[0] with itself), so it sends its registers
+            // shifted by one.
+            float mag_lo[17], mag_hi[16];
+            {
+                float2 pz[16];
+#pragma unroll
+                for (int k1 = 0; k1 < 16; ++k1) {
+                    const int j = 31 - k1;
+                    const float sx = lane0 ? z[(j + 1) & 31].x : z[j].x;
+                    const float sy = lane0 ? z[(j + 1) & 31].y : z[j].y;
+                    pz[k1].x = __int_as_float(__builtin_amdgcn_ds_bpermute(part_addr, __float_as_int(sx)));
+                    pz[k1].y = __int_as_float(__builtin_amdgcn_ds_bpermute(part_addr, __float_as_int(sy)));
+                }
+                float4 cq[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cq[j] = lds_read_b128(s_cs + j * 32 + l);
+                const float2 c512 = *s_cs512;
+#pragma unroll
+                for (int k1 = 0; k1 <= 16; ++k1) {
+                    const float2 zk = z[k1];
+                    const float2 zm = k1 < 16 ? pz[k1] : zk; // (k1 = 16: bin 512 pairs with itself; only lane 0's is a bin)
+                    const float2 w = k1 == 16 ? c512
+                                     : (k1 & 1) ? make_float2(cq[k1 >> 1].z, cq[k1 >> 1].w) : make_float2(cq[k1 >> 1].x, cq[k1 >> 1].y);
+                    const float sr = zk.x + zm.x, si = zk.y - zm.y;
+                    const float dr = zk.x - zm.x, di = zk.y + zm.y;
+                    const float tr = w.x * dr - w.y * di, ti = w.x * di + w.y * dr;
+                    const float ar = sr + tr, ai = si + ti;
+                    mag_lo[k1] = __builtin_amdgcn_sqrtf(ar * ar + ai * ai); // |X[k]| / W2
+                    if (k1 < 16) {
+                        const float br = sr - tr, bi = si - ti;
+                        mag_hi[k1] = __builtin_amdgcn_sqrtf(br * br + bi * bi); // |X[1024 - k]| / W2
+                    }
+                }
+            }
+            // ---- magnitudes into the plane (every transposition word has been read)
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) {
+                plane[l + 32 * k1] = mag_lo[k1];
+                plane[M - l - 32 * k1] = mag_hi[k1];
+            }
+            if (lane0) plane[M / 2] = mag_lo[16];
+            wave_sync();
+
+            // ---- mel filterbank on the frame's 32 lanes: per round every lane walks ONE filter's bins in ascending order,
+            // one chain of multiply-adds (mfcccpu.cpp:206-217); weights from the lane's own zero-padded row (16-byte
+            // reads), magnitudes as 8-byte reads from even starts spread over the banks by the host
+            {
+                float *lmf = lm + (f & 3) * nbp;
+                const float *wrow = s_mw + l * RS;
+                for (int r = 0; r < rounds; ++r) {
+                    const int st = s_mst[r * 32 + l], fid = s_mfid[r * 32 + l];
+                    const int L = p.mel32_L[r];
+                    const float *mg = plane + st;
+                    float acc = 0.f;
+                    int s2 = 0;
+                    for (; s2 + 16 <= L; s2 += 16) {
+                        float4 w[4];
+                        float2 mm[8];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) w[q] = lds_read_b128((const float4 *)(wrow + s2 + 4 * q));
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) mm[q] = lds_read_b64((const float2 *)(mg + s2 + 2 * q));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc += w[q].x * mm[2 * q].x;
+                            acc += w[q].y * mm[2 * q].y;
+                            acc += w[q].z * mm[2 * q + 1].x;
+                            acc += w[q].w * mm[2 * q + 1].y;
+                        }
+                    }
+                    for (; s2 < L; s2 += 8) {
+                        const float4 w0 = lds_read_b128((const float4 *)(wrow + s2));
+                        const float4 w1 = lds_read_b128((const float4 *)(wrow + s2 + 4));
+                        float2 mm[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) mm[q] = lds_read_b64((const float2 *)(mg + s2 + 2 * q));
+                        acc += w0.x * mm[0].x;
+                        acc += w0.y * mm[0].y;
+                        acc += w0.z * mm[1].x;
+                        acc += w0.w * mm[1].y;
+                        acc += w1.x * mm[2].x;
+                        acc += w1.y * mm[2].y;
+                        acc += w1.z * mm[3].x;
+                        acc += w1.w * mm[3].y;
+                    }
+                    wrow += L;
+                    lmf[fid >= 0 ? fid : nbp - 1] = MFX_LOG(fmaxf(acc, 1e-30f)); // idle lane: the row's spare word
+                }
+            }
+            wave_sync();
+
+            // ---- every 4th frame (and at the chunk's end): DCT-II + lifter of the waiting frames on the matrix pipe,
+            // D[row][c] = sum_m A[row][m] B[m][c] with frame g in rows 4g..4g+3, so register 0 of the result is out[g][c]
+            // on lane (g, c); tiles of 16 columns, K steps of 4 bands, two accumulator chains (as k_front_reg)
+            if ((f0 & 2) || last) {
+                const int g0 = f0 & ~3, gcount = (n_live - g0) < 4 ? (n_live - g0) : 4;
+                const int gi = lane >> 4, n = lane & 15;
+                float *orow = p.feat + (out_row + g0 + (gi < gcount ? gi : 0)) * (int64_t)p.feat_pitch;
+                if (p.dct_b) {
+                    const float *arow = lm + (n >> 2) * nbp + gi;
+                    const int ks = p.dct_ksteps;
+                    constexpr int TG = 3;
+                    for (int t0 = 0; t0 < p.dct_tiles; t0 += TG) {
+                        const int nt = p.dct_tiles - t0 < TG ? p.dct_tiles - t0 : TG;
+                        const float *bp = p.dct_b + (int64_t)t0 * ks * 64 + lane;
+                        f32x4 d0[TG], d1[TG];
+#pragma unroll
+                        for (int tt = 0; tt < TG; ++tt) d0[tt] = d1[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        for (int j0 = 0; j0 < ks; j0 += 8) {
+                            float bv[TG][8], av[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) av[u] = arow[j0 + u < ks ? 4 * (j0 + u) : 0];
+#pragma unroll
+                            for (int tt = 0; tt < TG; ++tt)
+#pragma unroll
+                                for (int u = 0; u < 8; ++u)
+                                    bv[tt][u] = (tt < nt && j0 + u < ks) ? bp[((int64_t)tt * ks + j0 + u) * 64] : 0.f;
+#pragma unroll
+                            for (int tt = 0; tt < TG; ++tt) {
+                                if (tt >= nt) break;
+#pragma unroll
+                                for (int u = 0; u < 8; u += 2) {
+                                    d0[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[tt][u], d0[tt], 0, 0, 0);
+                                    d1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[tt][u + 1], d1[tt], 0, 0, 0);
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int tt = 0; tt < TG; ++tt) {
+                            const int col = 16 * (t0 + tt) + n;
+                            if (tt < nt && gi < gcount && col < p.cols) orow[col] = d0[tt][0] + d1[tt][0];
+                        }
+                    }
+                } else { // no DCT: the log mel energies are the features
+                    for (int g = 0; g < gcount; ++g)
+                        for (int cc = lane; cc < p.cols; cc += 64)
+                            (p.feat + (out_row + g0 + g) * (int64_t)p.feat_pitch)[cc] = lm[g * nbp + cc];
+                }
+                wave_sync();
+            }
+        }
+        if (n_live <= 0) issue(cnxt, half); // empty chunk: its last iteration never ran, nothing was requested
+        c_cur = c_nxt;
+        ccur = cnxt;
+        c_nxt = draw();
+        cnxt = make_ctx(c_nxt);
+    }
+}
+
+} // namespace
+
+bool front2048_supported(int fft_size, int window_size, int num_banks, int cols, int channels)
+{
+    return fft_size == 2048 && window_size > 0 && window_size <= 64 * kRows2048 && (channels == 1 || channels == 2) &&
+           num_banks >= 1 && num_banks <= 256 && cols >= 1;
+}
+
+size_t front2048_lds_bytes(const FrontParams &p)
+{
+    const size_t f = front2048_table_floats(p.mel32_rounds, p.mel32_row_stride) +
+                     (size_t)kW2048 * (2 * kPlane + 4 * lm_stride(p.num_banks)) + 4;
+    return f * sizeof(float);
+}
+
+hipError_t launch_front2048(const FrontParams &p, int num_cus, hipStream_t stream)
+{
+    if (p.n_chunks <= 0) return hipSuccess;
+    const bool stereo = p.channels == 2;
+    if (!stereo && !p.pair_ok) return hipErrorInvalidValue; // mono: aligned sample pairs only (others stay on k_front_reg)
+    const size_t lds = front2048_lds_bytes(p);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const void *fn = stereo ? (const void *)k_front2048<true> : (const void *)k_front2048<false>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    int blocks = (p.n_chunks + kW2048 - 1) / kW2048;
+    if (blocks > num_cus) blocks = num_cus; // one block of 12 waves per CU
+    if (blocks < 1) blocks = 1;
+    if (stereo)
+        hipLaunchKernelGGL((k_front2048<true>), dim3(blocks), dim3(kW2048 * 64), lds, stream, p);
+    else
+        hipLaunchKernelGGL((k_front2048<false>), dim3(blocks), dim3(kW2048 * 64), lds, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace mfx

@@ -93,6 +93,12 @@ struct FrontParams {
     const int32_t *mel64_fid;     // [mel64_rounds][64]
     int32_t mel64_rounds, mel64_row_stride;
     int32_t mel64_L[8];
+    // two-frames-per-wave lane plan (k_front2048): filters dealt to the 32 lanes of a frame in rounds of 32
+    const float *mel32_w;         // [32][mel32_row_stride]
+    const int32_t *mel32_start;   // [mel32_rounds][32]
+    const int32_t *mel32_fid;     // [mel32_rounds][32]
+    int32_t mel32_rounds, mel32_row_stride;
+    int32_t mel32_L[8];
     // DCT on the matrix pipe: B operands [dct_tiles][dct_ksteps][64] (build_dct_mfma_operands), read from L1 / L2
     const float *dct_b;
     int32_t dct_tiles, dct_ksteps;
@@ -195,6 +201,12 @@ bool front512_supported(int fft_size, int window_size, int num_banks, int cols, 
 bool front1024_supported(int fft_size, int window_size, int num_banks, int cols, int channels, int ceps_len);
 size_t front1024_lds_bytes(const FrontParams &p);
 hipError_t launch_front1024(const FrontParams &p, bool aligned, int nm16, hipStream_t stream);
+
+// k_front2048 (mfx_front2048.hip): 2048-point transform of a window of at most 1152 samples, two frames per wave (32 lanes
+// each, 32 x 32 two-pass FFT), mono (aligned sample pairs) or interleaved stereo, mel -> log -> DCT fused, statics out
+bool front2048_supported(int fft_size, int window_size, int num_banks, int cols, int channels);
+size_t front2048_lds_bytes(const FrontParams &p);
+hipError_t launch_front2048(const FrontParams &p, int num_cus, hipStream_t stream);
 
 // symbol name of the dominant kernel for rocprofv3 (depends on the instantiation chosen)
 const char *front512_kernel_name(bool to_spectrum, bool aligned, int nm16);

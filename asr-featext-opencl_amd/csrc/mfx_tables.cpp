@@ -175,24 +175,25 @@ bool build_mel_lane_plan(const MelTable &t, int num_banks, int fft_size, int max
     return true;
 }
 
-bool build_mel_wave_plan(const MelTable &t, int num_banks, int fft_size, int max_read_bin, MelWavePlan &out)
+bool build_mel_wave_plan(const MelTable &t, int num_banks, int fft_size, int max_read_bin, MelWavePlan &out, int lanes)
 {
+    if (lanes != 64 && lanes != 32) return false;
     std::vector<int> order(num_banks);
     for (int m = 0; m < num_banks; ++m) order[m] = m;
     auto span = [&](int m) { return t.beg[m + 2] - t.beg[m]; };
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return span(a) > span(b); });
-    out.rounds = (num_banks + 63) / 64;
+    out.rounds = (num_banks + lanes - 1) / lanes;
     if (out.rounds > 8) return false;
-    out.start.assign((size_t)64 * out.rounds, 0);
-    out.fid.assign((size_t)64 * out.rounds, -1);
+    out.start.assign((size_t)lanes * out.rounds, 0);
+    out.fid.assign((size_t)lanes * out.rounds, -1);
     int total = 0;
     for (int r = 0; r < out.rounds; ++r) {
         // An 8-byte read is served in two groups of 32 lanes over 32 bank pairs: a group is conflict free when
         // (start / 2) mod 32 differs from lane to lane, so a clashing filter begins a few pairs early (zero weights).
         bool used[2][32] = {{false}};
         int longest = 0;
-        for (int j = 0; j < 64; ++j) {
-            const int idx = r * 64 + j;
+        for (int j = 0; j < lanes; ++j) {
+            const int idx = r * lanes + j;
             if (idx >= num_banks) continue;
             const int m = order[idx];
             const int b0 = t.beg[m], b1 = t.beg[m + 2];
@@ -206,21 +207,21 @@ bool build_mel_wave_plan(const MelTable &t, int num_banks, int fft_size, int max
                 }
             }
             used[j >> 5][(start >> 1) & 31] = true;
-            out.start[r * 64 + j] = start;
-            out.fid[r * 64 + j] = m;
+            out.start[r * lanes + j] = start;
+            out.fid[r * lanes + j] = m;
             longest = std::max(longest, b1 - start);
         }
         out.L[r] = std::max(8, (longest + 7) & ~7);
         total += out.L[r];
     }
     out.row_stride = stride_4odd(total);
-    out.w.assign((size_t)64 * out.row_stride, 0.0f);
+    out.w.assign((size_t)lanes * out.row_stride, 0.0f);
     int base = 0;
     for (int r = 0; r < out.rounds; ++r) {
-        for (int j = 0; j < 64; ++j) {
-            const int m = out.fid[r * 64 + j];
+        for (int j = 0; j < lanes; ++j) {
+            const int m = out.fid[r * lanes + j];
             if (m < 0) continue;
-            const int start = out.start[r * 64 + j];
+            const int start = out.start[r * lanes + j];
             if (start + out.L[r] - 1 > max_read_bin) return false;
             const float *row = t.weights.data() + (size_t)(m & 1) * fft_size;
             float *dst = out.w.data() + (size_t)j * out.row_stride + base;

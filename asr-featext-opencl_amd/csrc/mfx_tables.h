@@ -73,7 +73,9 @@ struct MelWavePlan {
     std::vector<int32_t> fid;
 };
 // false when it does not fit (more than 8 rounds, or a read past max_read_bin)
-bool build_mel_wave_plan(const MelTable &t, int num_banks, int fft_size, int max_read_bin, MelWavePlan &out);
+// lanes: 64 (one frame per wave, k_front_reg) or 32 (two frames per wave, k_front2048: the two halves of the wave walk
+// the same filters of their own frames); the arrays are [.][lanes]
+bool build_mel_wave_plan(const MelTable &t, int num_banks, int fft_size, int max_read_bin, MelWavePlan &out, int lanes = 64);
 
 // B operands of the DCT on the matrix pipe (v_mfma_f32_16x16x4_f32), for every tile of 16 output columns and every
 // K step of 4 mel bands: out[(tile * ksteps + j) * 64 + lane] = dct[4 j + (lane >> 4)][16 tile + (lane & 15)],

@@ -88,6 +88,7 @@ typedef struct mfx_config {
 
 /* mfx_config.engine bits */
 #define MFX_ENGINE_NO_FRONT1024 1 /* 1024-point short-window configurations stay on the generic long-transform kernel  */
+#define MFX_ENGINE_NO_FRONT2048 4 /* 2048-point short-window configurations stay on the generic long-transform kernel  */
 #define MFX_ENGINE_FUSE_DELTA 2   /* 512-point batch path: delta / delta-delta computed by a wave of the front-end kernel
                                      instead of the separate delta kernel (slower on MI355X)        */
 

@@ -1373,3 +1373,121 @@ def test_sliced_batch_then_large_streaming_download_on_one_handle(pkg, orc):
     m.batch_plan([u * L for u in range(n_utt)], [L] * n_utt)
     assert run() == 0 and np.array_equal(t_out.numpy(), first)
     m.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# k_front2048: 2048-point transforms of a short window, two frames per wave (BASELINE configs[4])
+# ---------------------------------------------------------------------------------------------
+
+_F2048 = [  # W, S, sr, nb, nc, c0, dyn, channels, alpha
+    (1102, 441, 44100.0, 128, 40, False, 2, 2, 1.0),     # configs[4] itself: stereo, odd shift
+    (1102, 441, 44100.0, 128, 40, False, 2, 1, 1.0),     # mono at an odd shift: stays on k_front_reg (not aligned pairs)
+    (1102, 440, 44100.0, 128, 40, False, 2, 1, 1.0),     # mono, aligned pairs
+    (1152, 400, 48000.0, 96, 24, True, 1, 2, 0.93),      # the longest window the kernel takes, c0, VTLN
+    (1025, 512, 44100.0, 40, 13, False, 0, 2, 1.0),      # odd window length, few filters, one DCT tile
+    (1100, 300, 32000.0, 200, 60, False, 2, 1, 1.07),    # 7 rounds of 32 filters, 4 DCT tiles
+    (1050, 350, 44100.0, 64, 0, False, 1, 2, 1.0),       # log mel energies as the features (no DCT)
+]
+
+
+@pytest.mark.parametrize("W,S,sr,nb,nc,c0,dyn,ch,alpha", _F2048)
+def test_front2048_configurations(pkg, orc, W, S, sr, nb, nc, c0, dyn, ch, alpha):
+    """Ragged utterances (1, 2, 3, 15, 16, 17, 33, 70 frames: odd counts leave the wave's upper half idle, 1-frame chunks,
+    chunk ends off the 4-frame DCT groups) at arbitrary offsets through the batch entry against the oracle fed each
+    utterance alone, and the same batch through k_front_reg (mfx_config.engine = MFX_ENGINE_NO_FRONT2048: the 16.16.4
+    factorisation of the same transform)."""
+    rng = np.random.default_rng(W + S + nb)
+    frames = [1, 2, 3, 15, 16, 17, 33, 70]
+    step = 2 if (ch == 1 and S % 2 == 0) else 1          # mono pairs: even offsets keep the aligned path
+    lens = [(T - 1) * S + W + int(rng.integers(0, S)) for T in frames]
+    offs, pos = [], 0
+    for n in lens:
+        offs.append(pos)
+        pos += n + step * int(rng.integers(0, 3))
+        pos += pos % step
+    mono = np.zeros(pos, np.int16)
+    if ch == 2:
+        left = np.zeros(pos, np.int16)
+        right = np.zeros(pos, np.int16)
+    for i, (o_, n) in enumerate(zip(offs, lens)):
+        if ch == 2:
+            left[o_:o_ + n] = synth_utterance(n, 700 + 2 * i, sr=sr)
+            right[o_:o_ + n] = synth_utterance(n, 701 + 2 * i, sr=sr, f=311.0 + 40 * i)
+        else:
+            mono[o_:o_ + n] = synth_utterance(n, 700 + i, sr=sr)
+    if ch == 2:
+        mono = ((left.astype(np.int32) + right.astype(np.int32)) >> 1).astype(np.int16)
+        pcm = np.empty(2 * pos, np.int16)
+        pcm[0::2], pcm[1::2] = left, right
+    else:
+        pcm = mono
+    kw = dict(W=W, S=S, nb=nb, sr=sr, nc=nc, c0=c0, dyn=dyn, l1=2, l2=2, channels=ch)
+    m, cfg, w = make_pair(pkg, orc, max(lens) + 2000, **kw)
+    assert m.fft_size() == 2048
+    if alpha != 1.0:
+        m.set_alpha(alpha)
+    rows, total = m.batch_plan(offs, lens)
+    aligned = ch == 2 or (S % 2 == 0)
+    assert m.dominant_kernel_name() == ("k_front2048" if aligned else "k_front_reg")
+    got = m.batch_run_host(pcm)
+    assert total == sum(frames) and got.shape[0] == total
+    g = groups_of(dyn)
+    m2, _, _ = make_pair(pkg, orc, max(lens) + 2000, engine=pkg.mfcc.ENGINE_NO_FRONT2048, **kw)
+    assert m2.dominant_kernel_name() == "k_front_reg"
+    if alpha != 1.0:
+        m2.set_alpha(alpha)
+    m2.batch_plan(offs, lens)
+    assert_close(got, m2.batch_run_host(pcm), "k_front2048 vs k_front_reg", groups=g)
+    for i, (o_, n, T) in enumerate(zip(offs, lens, frames)):
+        o = orc.OracleMfcc(cfg, w, bug_compat=False)
+        o.set_alpha(alpha)
+        D = (2 + (2 if dyn == 2 else 0)) if dyn else 0
+        if T <= D:
+            continue                                      # the streaming reference refuses files of at most D frames
+        want = orc.run_utterance(cfg, mono[o_:o_ + n], w, alpha=alpha, bug_compat=False)
+        assert want.shape[0] == T
+        assert_close(got[rows[i]:rows[i] + T], want, "utterance %d (%d frames)" % (i, T), groups=g)
+
+
+def test_c5_full_size_properties(pkg, orc):
+    """BASELINE configs[4] at full size on one GPU: 200 stereo utterances x 10 s at 44.1 kHz (441 000 samples per channel)
+    -> 199 600 frames x 120.  Every row written and finite, duplicate utterances give the same bits wherever they sit,
+    a second pass and a split batch reproduce the first bit for bit, silence gives exact-zero deltas, and sampled
+    utterances agree with the oracle."""
+    import torch
+    n_utt, n = 200, 441000
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    pcm = (3000.0 * torch.randn((n_utt, n, 2), generator=g, device=dev)).round().clamp(-32768, 32767).to(torch.int16)
+    pcm[100] = pcm[7]
+    pcm[199] = pcm[7]
+    pcm[31] = 0
+    m, cfg, w = make_pair(pkg, orc, n + 1000, W=1102, S=441, nb=128, sr=44100.0, nc=40, dyn=2, channels=2)
+    rows, total = m.batch_plan(np.arange(n_utt) * n, np.full(n_utt, n))
+    T = (n - (1102 - 441)) // 441
+    assert total == n_utt * T == 199600 and m.dominant_kernel_name() == "k_front2048"
+    out = torch.full((total, 120), float("nan"), dtype=torch.float32, device=dev)
+    m.batch_run_device(pcm.data_ptr(), n_utt * n, out.data_ptr())
+    m.synchronize()
+    assert bool(torch.isfinite(out).all())
+    o7 = out[rows[7]:rows[7] + T]
+    assert torch.equal(o7, out[rows[100]:rows[100] + T]) and torch.equal(o7, out[rows[199]:rows[199] + T])
+    sil = out[rows[31]:rows[31] + T]
+    assert bool((sil[:, 40:] == 0).all()) and float(sil[:, :40].abs().max()) <= 1e-4 * 69.08
+    out2 = torch.empty_like(out)
+    m.batch_run_device(pcm.data_ptr(), n_utt * n, out2.data_ptr())
+    m.synchronize()
+    assert torch.equal(out, out2)
+    m2, _, _ = make_pair(pkg, orc, n + 1000, W=1102, S=441, nb=128, sr=44100.0, nc=40, dyn=2, channels=2)
+    half = 77
+    r2, t2 = m2.batch_plan(np.arange(half) * n, np.full(half, n))
+    outa = torch.empty((t2, 120), dtype=torch.float32, device=dev)
+    m2.batch_run_device(pcm.data_ptr(), n_utt * n, outa.data_ptr())
+    m2.synchronize()
+    assert torch.equal(outa, out[:t2])
+    for u in (0, 7, 150):
+        x = pcm[u].cpu().numpy().astype(np.int32)
+        mono = ((x[:, 0] + x[:, 1]) >> 1).astype(np.int16)
+        want = orc.run_utterance(cfg, mono, w, bug_compat=False)
+        assert_close(out[rows[u]:rows[u] + T].cpu().numpy(), want, "C5 utt %d" % u, groups=3)
