@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(kW2048 * 64, 3) k_front2048(FrontParams p)
     constexpr int M = 1024, NR = kRows2048;
     constexpr int NWORD = STEREO ? 2 * NR : NR; // raw 32-bit words per lane and frame
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
     const int l = lane & 31, half = lane >> 5;
     const int nb = p.num_banks;
     const int RS = p.mel32_row_stride, rounds = p.mel32_rounds;
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(kW2048 * 64, 3) k_front2048(FrontParams p)
     float *s_wave = (float *)(s_mfid + 32 * rounds) + wave * (2 * kPlane + 4 * nbp);
     float *plane = s_wave + half * kPlane;                         // this frame's plane
     float *lm = s_wave + 2 * kPlane;                               // [4][nbp]
-    int *s_ctr = (int *)((float *)(s_mfid + 32 * rounds) + kW2048 * (2 * kPlane + 4 * nbp));
+    int *s_ctr = (int *)((float *)(s_mfid + 32 * rounds) + n_waves * (2 * kPlane + 4 * nbp));
     if (tid == 0) *s_ctr = 0;
 
     const float scale = p.scale; // 0.5 / W2 (a power of two: exact)
@@ -242,23 +242,17 @@ __global__ void __launch_bounds__(kW2048 * 64, 3) k_front2048(FrontParams p)
                 const float2 w = s_win[l + 32 * j];
                 z[j] = make_float2(w.x * x0, w.y * x1);
             }
-            // the next two frames of this chunk or, from its last iteration, the first two of the next chunk: requested
-            // now, unconditionally, into the registers just consumed
-            if (last)
-                issue(cnxt, half);
-            else
-                issue(ccur, f + 2);
-
             // ---- pass 1 + inter-pass twiddle
             fft32(z);
-            {
-                float4 tq[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) tq[j] = lds_read_b128(s_tw + j * 32 + l);
+            for (int j0 = 0; j0 < 16; j0 += 4) { // (4 table words in flight at a time: 16 registers, not 64)
+                float4 tq[4];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    if (j > 0) z[2 * j] = cmul(z[2 * j], make_float2(tq[j].x, tq[j].y));
-                    z[2 * j + 1] = cmul(z[2 * j + 1], make_float2(tq[j].z, tq[j].w));
+                for (int j = 0; j < 4; ++j) tq[j] = lds_read_b128(s_tw + (j0 + j) * 32 + l);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j0 + j > 0) z[2 * (j0 + j)] = cmul(z[2 * (j0 + j)], make_float2(tq[j].x, tq[j].y));
+                    z[2 * (j0 + j) + 1] = cmul(z[2 * (j0 + j) + 1], make_float2(tq[j].z, tq[j].w));
                 }
             }
             // ---- 32 x 32 transposition through the frame's plane: real parts, then imaginary parts.  The LDS executes a
@@ -287,45 +281,47 @@ __global__ void __launch_bounds__(kW2048 * 64, 3) k_front2048(FrontParams p)
             // ---- real split over the pairs (k, 1024 - k), k = l + 32 k1, k1 < 16.  Z[1024 - k] is register 31 - k1 of
             // lane 32 - l; lane 0 pairs with itself: register 32 - k1 (and Z[0] with itself), so it sends its registers
             // shifted by one.
-            float mag_lo[17], mag_hi[16];
-            {
-                float2 pz[16];
+            // The magnitudes go straight into the frame's plane (every transposition word has been read), 8 pairs at a time.
 #pragma unroll
-                for (int k1 = 0; k1 < 16; ++k1) {
-                    const int j = 31 - k1;
+            for (int h8 = 0; h8 < 2; ++h8) {
+                float2 pz[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int j = 31 - (8 * h8 + i);
                     const float sx = lane0 ? z[(j + 1) & 31].x : z[j].x;
                     const float sy = lane0 ? z[(j + 1) & 31].y : z[j].y;
-                    pz[k1].x = __int_as_float(__builtin_amdgcn_ds_bpermute(part_addr, __float_as_int(sx)));
-                    pz[k1].y = __int_as_float(__builtin_amdgcn_ds_bpermute(part_addr, __float_as_int(sy)));
+                    pz[i].x = __int_as_float(__builtin_amdgcn_ds_bpermute(part_addr, __float_as_int(sx)));
+                    pz[i].y = __int_as_float(__builtin_amdgcn_ds_bpermute(part_addr, __float_as_int(sy)));
                 }
-                float4 cq[8];
+                float4 cq[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) cq[j] = lds_read_b128(s_cs + j * 32 + l);
-                const float2 c512 = *s_cs512;
+                for (int j = 0; j < 4; ++j) cq[j] = lds_read_b128(s_cs + (4 * h8 + j) * 32 + l);
 #pragma unroll
-                for (int k1 = 0; k1 <= 16; ++k1) {
-                    const float2 zk = z[k1];
-                    const float2 zm = k1 < 16 ? pz[k1] : zk; // (k1 = 16: bin 512 pairs with itself; only lane 0's is a bin)
-                    const float2 w = k1 == 16 ? c512
-                                     : (k1 & 1) ? make_float2(cq[k1 >> 1].z, cq[k1 >> 1].w) : make_float2(cq[k1 >> 1].x, cq[k1 >> 1].y);
+                for (int i = 0; i < 8; ++i) {
+                    const int k1 = 8 * h8 + i;
+                    const float2 zk = z[k1], zm = pz[i];
+                    const float2 w = (i & 1) ? make_float2(cq[i >> 1].z, cq[i >> 1].w) : make_float2(cq[i >> 1].x, cq[i >> 1].y);
                     const float sr = zk.x + zm.x, si = zk.y - zm.y;
                     const float dr = zk.x - zm.x, di = zk.y + zm.y;
                     const float tr = w.x * dr - w.y * di, ti = w.x * di + w.y * dr;
-                    const float ar = sr + tr, ai = si + ti;
-                    mag_lo[k1] = __builtin_amdgcn_sqrtf(ar * ar + ai * ai); // |X[k]| / W2
-                    if (k1 < 16) {
-                        const float br = sr - tr, bi = si - ti;
-                        mag_hi[k1] = __builtin_amdgcn_sqrtf(br * br + bi * bi); // |X[1024 - k]| / W2
-                    }
+                    const float ar = sr + tr, ai = si + ti, br = sr - tr, bi = si - ti;
+                    plane[l + 32 * k1] = __builtin_amdgcn_sqrtf(ar * ar + ai * ai);     // |X[k]| / W2
+                    plane[M - l - 32 * k1] = __builtin_amdgcn_sqrtf(br * br + bi * bi); // |X[1024 - k]| / W2
                 }
             }
-            // ---- magnitudes into the plane (every transposition word has been read)
-#pragma unroll
-            for (int k1 = 0; k1 < 16; ++k1) {
-                plane[l + 32 * k1] = mag_lo[k1];
-                plane[M - l - 32 * k1] = mag_hi[k1];
+            { // bin 512 pairs with itself: Z[512] is register 16 of lane 0 (S = 2 Re, T = cs[512] * 2i Im)
+                const float2 zk = z[16], w = *s_cs512;
+                const float sr = zk.x + zk.x, di = zk.y + zk.y;
+                const float tr = -w.y * di, ti = w.x * di;
+                const float ar = sr + tr;
+                if (lane0) plane[M / 2] = __builtin_amdgcn_sqrtf(ar * ar + ti * ti);
             }
-            if (lane0) plane[M / 2] = mag_lo[16];
+            // the next two frames of this chunk or, from its last iteration, the first two of the next chunk: requested here,
+            // unconditionally, where few registers are live -- the words arrive under the mel walk and the DCT
+            if (last)
+                issue(cnxt, half);
+            else
+                issue(ccur, f + 2);
             wave_sync();
 
             // ---- mel filterbank on the frame's 32 lanes: per round every lane walks ONE filter's bins in ascending order,
@@ -442,11 +438,26 @@ bool front2048_supported(int fft_size, int window_size, int num_banks, int cols,
            num_banks >= 1 && num_banks <= 256 && cols >= 1;
 }
 
-size_t front2048_lds_bytes(const FrontParams &p)
+namespace {
+size_t lds_bytes_2048(const FrontParams &p, int n_waves)
 {
     const size_t f = front2048_table_floats(p.mel32_rounds, p.mel32_row_stride) +
-                     (size_t)kW2048 * (2 * kPlane + 4 * lm_stride(p.num_banks)) + 4;
+                     (size_t)n_waves * (2 * kPlane + 4 * lm_stride(p.num_banks)) + 4;
     return f * sizeof(float);
+}
+// waves per block (one block per CU): as many of 12 as the CU's 160 KB of LDS hold, at least 6 (0: does not fit)
+int waves_2048(const FrontParams &p)
+{
+    for (int nw = kW2048; nw >= 6; --nw)
+        if (lds_bytes_2048(p, nw) <= 160 * 1024) return nw;
+    return 0;
+}
+} // namespace
+
+size_t front2048_lds_bytes(const FrontParams &p)
+{
+    const int nw = waves_2048(p);
+    return nw ? lds_bytes_2048(p, nw) : (size_t)1 << 30;
 }
 
 hipError_t launch_front2048(const FrontParams &p, int num_cus, hipStream_t stream)
@@ -454,20 +465,21 @@ hipError_t launch_front2048(const FrontParams &p, int num_cus, hipStream_t strea
     if (p.n_chunks <= 0) return hipSuccess;
     const bool stereo = p.channels == 2;
     if (!stereo && !p.pair_ok) return hipErrorInvalidValue; // mono: aligned sample pairs only (others stay on k_front_reg)
-    const size_t lds = front2048_lds_bytes(p);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const int nw = waves_2048(p);
+    if (nw == 0) return hipErrorInvalidValue;
+    const size_t lds = lds_bytes_2048(p, nw);
     const void *fn = stereo ? (const void *)k_front2048<true> : (const void *)k_front2048<false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    int blocks = (p.n_chunks + kW2048 - 1) / kW2048;
-    if (blocks > num_cus) blocks = num_cus; // one block of 12 waves per CU
+    int blocks = (p.n_chunks + nw - 1) / nw;
+    if (blocks > num_cus) blocks = num_cus; // one block of up to 12 waves per CU
     if (blocks < 1) blocks = 1;
     if (stereo)
-        hipLaunchKernelGGL((k_front2048<true>), dim3(blocks), dim3(kW2048 * 64), lds, stream, p);
+        hipLaunchKernelGGL((k_front2048<true>), dim3(blocks), dim3(nw * 64), lds, stream, p);
     else
-        hipLaunchKernelGGL((k_front2048<false>), dim3(blocks), dim3(kW2048 * 64), lds, stream, p);
+        hipLaunchKernelGGL((k_front2048<false>), dim3(blocks), dim3(nw * 64), lds, stream, p);
     return hipGetLastError();
 }
 

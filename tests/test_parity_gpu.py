@@ -1385,7 +1385,7 @@ _F2048 = [  # W, S, sr, nb, nc, c0, dyn, channels, alpha
     (1102, 440, 44100.0, 128, 40, False, 2, 1, 1.0),     # mono, aligned pairs
     (1152, 400, 48000.0, 96, 24, True, 1, 2, 0.93),      # the longest window the kernel takes, c0, VTLN
     (1025, 512, 44100.0, 40, 13, False, 0, 2, 1.0),      # odd window length, few filters, one DCT tile
-    (1100, 300, 32000.0, 200, 60, False, 2, 1, 1.07),    # 7 rounds of 32 filters, 4 DCT tiles
+    (1100, 300, 32000.0, 200, 60, False, 2, 1, 1.07),    # 7 rounds of 32 filters, 4 DCT tiles; fewer waves per block (LDS)
     (1050, 350, 44100.0, 64, 0, False, 1, 2, 1.0),       # log mel energies as the features (no DCT)
 ]
 
@@ -1442,8 +1442,8 @@ def test_front2048_configurations(pkg, orc, W, S, sr, nb, nc, c0, dyn, ch, alpha
         o = orc.OracleMfcc(cfg, w, bug_compat=False)
         o.set_alpha(alpha)
         D = (2 + (2 if dyn == 2 else 0)) if dyn else 0
-        if T <= D:
-            continue                                      # the streaming reference refuses files of at most D frames
+        if T <= 2 * D:
+            continue   # files of fewer than 2 D frames: the streaming reference refuses them or leaves its frame grid
         want = orc.run_utterance(cfg, mono[o_:o_ + n], w, alpha=alpha, bug_compat=False)
         assert want.shape[0] == T
         assert_close(got[rows[i]:rows[i] + T], want, "utterance %d (%d frames)" % (i, T), groups=g)
