@@ -84,6 +84,7 @@ struct mfx_handle {
     bool wplan_ok = false;
     DevBuf<float> d_mel64_w, d_dct_b;
     DevBuf<int32_t> d_mel64_start, d_mel64_fid;
+    DevBuf<float> d_dct_b4;                          // k_front2048: DCT operands as 16-byte words
     DevBuf<float> d_mel32_w;                         // k_front2048: the 32-lane plan
     DevBuf<int32_t> d_mel32_start, d_mel32_fid;
     MelWavePlan wplan32;
@@ -253,6 +254,7 @@ int refresh_mel(mfx_handle *h)
             FrontParams probe;
             std::memset(&probe, 0, sizeof(probe));
             probe.num_banks = h->nb;
+            probe.dct_ksteps = h->ceps > 0 ? (h->nb + 3) / 4 : 0;
             probe.mel32_rounds = h->wplan32.rounds;
             probe.mel32_row_stride = h->wplan32.row_stride;
             h->wplan32_ok = front2048_lds_bytes(probe) <= 160 * 1024;
@@ -310,6 +312,7 @@ void fill_front(const mfx_handle *h, FrontParams &p)
     p.mel32_row_stride = h->wplan32_ok ? h->wplan32.row_stride : 0;
     for (int i = 0; i < 8; ++i) p.mel32_L[i] = h->wplan32.L[i];
     p.dct_b = h->ceps > 0 ? h->d_dct_b.p : nullptr;
+    p.dct_b4 = h->ceps > 0 ? h->d_dct_b4.p : nullptr;
     p.dct_tiles = h->dct_tiles;
     p.dct_ksteps = h->dct_ksteps;
     p.dct_stride = h->dct_stride;
@@ -442,6 +445,7 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_mel64_fid.release();
     h->d_dct_b.release();
     h->d_mel32_w.release();
+    h->d_dct_b4.release();
     h->d_mel32_start.release();
     h->d_mel32_fid.release();
     h->d_dct_t.release();
@@ -626,6 +630,10 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
                 std::vector<float> ob;
                 build_dct_mfma_operands(m, h->nb, h->dl, h->dct_tiles, h->dct_ksteps, ob);
                 if (upload(h->d_dct_b, ob) != hipSuccess) return bail(MFX_ERR_DEVICE);
+                if (h->fast2048) {
+                    build_dct_mfma_operands4(m, h->nb, h->dl, ob);
+                    if (upload(h->d_dct_b4, ob) != hipSuccess) return bail(MFX_ERR_DEVICE);
+                }
             }
             if (h->fast512) {
                 std::vector<float> mt;
@@ -1496,11 +1504,14 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
     // The 512-point kernel deals chunks to the 16 waves of each block as they become free; with 16-frame
     // chunks a wave can sit idle for most of a chunk time (~34 us on C2) at the end of the launch.  The last two
     // chunks of every wave of the grid are therefore cut into 4-frame pieces (one kernel iteration each).
+    // (k_front2048: 12 waves per CU, each 16-frame chunk is 8 iterations of ~10 us -- on C5 a wave sees only ~4 chunks in
+    // all, so the last ONE per wave is cut, and a launch twice that long already qualifies)
     const int ts = h->cfg.tail_split;
-    if ((h->fast512 || (h->fast1024 && h->fused_ok)) && ts >= 0) {
+    const bool f2048 = h->fast2048 && h->wplan32_ok && (h->channels == 2 || (aligned && (h->S % 2) == 0 && (h->W % 2) == 0));
+    if ((h->fast512 || (h->fast1024 && h->fused_ok) || f2048) && ts >= 0) {
         const size_t n = h->h_chunks.size();
-        const size_t tail = std::min<size_t>(n, (size_t)(ts > 0 ? std::min(ts, 64) : 2) * 16 * h->num_cus);
-        if (n >= 4 * tail) { // only when the launch is long enough for the tail to matter
+        const size_t tail = std::min<size_t>(n, (size_t)(ts > 0 ? std::min(ts, 64) : f2048 ? 1 : 2) * (f2048 ? 12 : 16) * h->num_cus);
+        if (n >= (f2048 ? 2 : 4) * tail) { // only when the launch is long enough for the tail to matter
             std::vector<Chunk> cut;
             std::vector<int32_t> cut_utt;
             for (size_t c = n - tail; c < n; ++c) {
@@ -1642,6 +1653,7 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
         ProfScope ps(h);
         HIP_TRY(h, launch_front1024(p, h->batch_aligned, h->nm16, h->stream));
     } else if (fused2048) {
+        p.spec = h->d_spec.p; // unused by the fused kernel; a -DMFX_STAMPS dev build drops its cycle sums here
         ProfScope ps(h);
         HIP_TRY(h, launch_front2048(p, h->num_cus, h->stream));
     } else if (fusedgen) {

@@ -37,7 +37,26 @@ namespace mfx {
 
 namespace {
 
-constexpr int kW2048 = 12;        // waves per block; one block per CU (LDS: ~33 KB of tables + 10.5 KB per wave)
+// Dev-only in-kernel stamps (-DMFX_STAMPS): per-wave cycle sums per phase, written by lane 0 to p.spec (unused by the
+// fused path); tools/stamps2048.py reads them.  Never part of a timed build.
+#ifdef MFX_STAMPS
+#define MFX_STAMP2(i)                                                                  \
+    do {                                                                               \
+        unsigned long long t_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        st_acc[i] += t_ - st_last;                                                     \
+        st_last = t_;                                                                  \
+    } while (0)
+#else
+#define MFX_STAMP2(i)
+#endif
+
+#ifndef MFX_W2048
+#define MFX_W2048 12
+#endif
+constexpr int kW2048 = MFX_W2048;        // waves per block; one block per CU (LDS: ~33 KB of tables + 10.5 KB per wave)
 constexpr int kPlane = 1040;      // floats per frame plane: 1024 transposition words / 1025 magnitudes + finite slack
 constexpr int kRows2048 = 18;     // rows of 32 sample pairs that can carry window taps: W <= 1152
 
@@ -89,6 +108,15 @@ __device__ __forceinline__ void fft32(float2 (&x)[32])
     }
 }
 
+// Log mel energies of 4 frames waiting for the DCT: lm[g * FS + m]; FS = 4 q with q odd and FS > nb (the last word parks
+// idle lanes): the four frames' 16-byte operand reads then fall on distinct bank quads.
+__host__ __device__ inline int lm_fs4(int nb)
+{
+    int q = (nb + 4) / 4 + ((nb + 4) % 4 ? 1 : 0);
+    if ((q & 1) == 0) ++q;
+    return 4 * q;
+}
+
 // LDS floats: shared tables, then per wave two planes and the log mel energies of 4 frames
 __host__ __device__ inline size_t front2048_table_floats(int rounds, int row_stride)
 {
@@ -99,8 +127,51 @@ __host__ __device__ inline size_t front2048_table_floats(int rounds, int row_str
            + (size_t)64 * rounds;             // starts + filter ids
 }
 
+// DCT-II + lifter of 4 frames on the matrix pipe, 64 output columns at a time: v_mfma_f32_4x4x1_16b_f32 computes 16
+// independent 4 x 4 outer products, D_b[i][j] += A_b[i] * B_b[j]; with i = frame, b = lane / 4, j = lane % 4 one
+// instruction adds ONE band m to out[frame i][column 4 b + j] for all 64 columns and all 4 frames:
+//     A operand of lane l: lm[frame l & 3][m]          B operand of lane l: dct[m][64 tile + l]
+//     result register i of lane l: out[frame i][64 tile + l]
+// Every product of the instruction is used when the row has 64 columns (40 here: 62 %), where the 16 x 16 x 4 form with
+// 4 frames used a quarter of its rows -- and on gfx950 f32 matrix instructions do not overlap the vector pipe
+// (SQ_VALU_MFMA_COEXEC_CYCLES = 0: they run on the same FP32 units), so their cycles are the SIMD's cycles: 8 per band
+// for four frames here against 32 per 4 bands and 16 columns before (C5: 3072 -> 1024 SIMD cycles per four frames).
+// Bands are accumulated in ascending order in two chains (even / odd m), as mfcccpu.cpp:222-232 sums them up to that
+// association.  Operands come four bands at a time (one 16-byte LDS read, one 16-byte buffer load; B laid out
+// [tile][band / 4][lane][4], bands past the table return 0), software pipelined without branches: the next four bands'
+// operands are requested before the current four instructions issue.
+__device__ __forceinline__ void dct_mfma4(const float *arow, __amdgpu_buffer_rsrc_t rsrc, int table_bytes, int lane, int tile,
+                                          int ks, float (&res)[4])
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+    float4 ava, avb;
+    u32x4 bva, bvb;
+    auto fetch = [&](u32x4 &bv, float4 &av, int j4) {
+        av = lds_read_b128((const float4 *)(arow + 4 * (j4 < ks ? j4 : 0)));
+        bv = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, j4 < ks ? ((tile * ks + j4) * 1024) : table_bytes, 0);
+    };
+    auto mac = [&](const u32x4 &bv, const float4 &av) {
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, __uint_as_float(bv[0]), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, __uint_as_float(bv[1]), d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, __uint_as_float(bv[2]), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, __uint_as_float(bv[3]), d1, 0, 0, 0);
+    };
+    fetch(bva, ava, 0);
+    for (int j4 = 0; j4 < ks; j4 += 2) {
+        fetch(bvb, avb, j4 + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mac(bva, ava);
+        fetch(bva, ava, j4 + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mac(bvb, avb);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) res[i] = d0[i] + d1[i];
+}
+
 template <bool STEREO>
-__global__ void __launch_bounds__(kW2048 * 64, 3) k_front2048(FrontParams p)
+__global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(FrontParams p)
 {
     constexpr int M = 1024, NR = kRows2048;
     constexpr int NWORD = STEREO ? 2 * NR : NR; // raw 32-bit words per lane and frame
@@ -109,7 +180,8 @@ __global__ void __launch_bounds__(kW2048 * 64, 3) k_front2048(FrontParams p)
     const int l = lane & 31, half = lane >> 5;
     const int nb = p.num_banks;
     const int RS = p.mel32_row_stride, rounds = p.mel32_rounds;
-    const int nbp = lm_stride(nb);
+    const int lmFS = lm_fs4(nb);
+    const int lm_wave = 4 * lmFS; // floats of the 4 waiting frames
 
     float2 *s_win = (float2 *)smem;                                // [18][32] (w[2n], w[2n+1]) * 0.5 / W2
     float4 *s_tw = (float4 *)(s_win + 32 * NR);                    // [16][32] (W_1024^(n1 2j), W_1024^(n1 (2j+1)))
@@ -118,10 +190,10 @@ __global__ void __launch_bounds__(kW2048 * 64, 3) k_front2048(FrontParams p)
     float *s_mw = (float *)(s_cs512 + 2);                          // [32][RS]
     int *s_mst = (int *)(s_mw + 32 * RS);                          // [rounds][32]
     int *s_mfid = s_mst + 32 * rounds;                             // [rounds][32]
-    float *s_wave = (float *)(s_mfid + 32 * rounds) + wave * (2 * kPlane + 4 * nbp);
+    float *s_wave = (float *)(s_mfid + 32 * rounds) + wave * (2 * kPlane + lm_wave);
     float *plane = s_wave + half * kPlane;                         // this frame's plane
-    float *lm = s_wave + 2 * kPlane;                               // [4][nbp]
-    int *s_ctr = (int *)((float *)(s_mfid + 32 * rounds) + n_waves * (2 * kPlane + 4 * nbp));
+    float *lm = s_wave + 2 * kPlane;                               // [4][lmFS] (lm_fs4)
+    int *s_ctr = (int *)((float *)(s_mfid + 32 * rounds) + n_waves * (2 * kPlane + lm_wave));
     if (tid == 0) *s_ctr = 0;
 
     const float scale = p.scale; // 0.5 / W2 (a power of two: exact)
@@ -147,7 +219,7 @@ __global__ void __launch_bounds__(kW2048 * 64, 3) k_front2048(FrontParams p)
         s_mst[i] = p.mel32_start[i];
         s_mfid[i] = p.mel32_fid[i];
     }
-    for (int i = lane; i < 2 * kPlane + 4 * nbp; i += 64) s_wave[i] = 0.f; // (words the walk may read but nothing writes)
+    for (int i = lane; i < 2 * kPlane + lm_wave; i += 64) s_wave[i] = 0.f; // (words the walk may read but nothing writes)
     __syncthreads();
 
     // ---- per-lane constants
@@ -212,6 +284,27 @@ __global__ void __launch_bounds__(kW2048 * 64, 3) k_front2048(FrontParams p)
         }
     };
 
+#ifdef MFX_STAMPS
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_rt0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt0)::"memory");
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
+    // Stagger: the waves of a block run the same program and, started together, stay in step -- all of a SIMD's waves in
+    // the FFT (vector pipe), then all in the mel walk (LDS), then all in the DCT (matrix pipe), each phase taking three
+    // times what one wave needs (in-kernel stamps: 6.5 cycles per vector instruction in pass 1, 108 per matrix
+    // instruction).  Waves w, w + 4, w + 8 share a SIMD: the second and third group start a third / two thirds of an
+    // iteration late, so that one SIMD's waves are in different phases.
+#ifndef MFX_STAGGER2048
+#define MFX_STAGGER2048 0
+#endif
+    if (MFX_STAGGER2048 > 0) {
+        const int naps = (wave >> 2) * (MFX_STAGGER2048 / 64 / 100);
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(100); // 100 x 64 cycles
+    }
+    // the DCT's B operands [tiles][ksteps][64] through a buffer descriptor (offsets past the table return 0)
+    const int dct_ks = p.dct_ksteps, dct_tiles64 = (p.dct_len + 63) >> 6; // bands / 4; groups of 64 output columns
+    const int dct_bytes = p.dct_b4 ? dct_tiles64 * dct_ks * 1024 : 0;
+    const __amdgpu_buffer_rsrc_t dct_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.dct_b4, 0, dct_bytes, 0x00020000);
     int c_cur = draw(), c_nxt = draw();
     ChunkCtx ccur = make_ctx(c_cur), cnxt = make_ctx(c_nxt);
     issue(ccur, half);
@@ -221,6 +314,7 @@ __global__ void __launch_bounds__(kW2048 * 64, 3) k_front2048(FrontParams p)
         for (int f0 = 0; f0 < n_live; f0 += 2) {
             const int f = f0 + half;
             const bool last = f0 + 2 >= n_live;
+            MFX_STAMP2(0);
             // ---- framing + window: z[n2] = (w[2n] x[2n], w[2n+1] x[2n+1]), n = l + 32 n2
             float2 z[32];
 #pragma unroll
@@ -242,6 +336,7 @@ __global__ void __launch_bounds__(kW2048 * 64, 3) k_front2048(FrontParams p)
                 const float2 w = s_win[l + 32 * j];
                 z[j] = make_float2(w.x * x0, w.y * x1);
             }
+            MFX_STAMP2(1);
             // ---- pass 1 + inter-pass twiddle
             fft32(z);
 #pragma unroll
@@ -257,6 +352,7 @@ __global__ void __launch_bounds__(kW2048 * 64, 3) k_front2048(FrontParams p)
             }
             // ---- 32 x 32 transposition through the frame's plane: real parts, then imaginary parts.  The LDS executes a
             // wave's instructions in order, so the imaginary parts' writes need not wait for the real parts' reads.
+            MFX_STAMP2(2);
             float zr[32], zi[32];
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -275,8 +371,10 @@ __global__ void __launch_bounds__(kW2048 * 64, 3) k_front2048(FrontParams p)
 #pragma unroll
             for (int n1 = 0; n1 < 32; ++n1) z[n1] = make_float2(zr[n1], zi[n1]);
 
+            MFX_STAMP2(3);
             // ---- pass 2: lane k2 = l now holds Z[l + 32 k1] in z[k1]
             fft32(z);
+            MFX_STAMP2(4);
 
             // ---- real split over the pairs (k, 1024 - k), k = l + 32 k1, k1 < 16.  Z[1024 - k] is register 31 - k1 of
             // lane 32 - l; lane 0 pairs with itself: register 32 - k1 (and Z[0] with itself), so it sends its registers
@@ -324,13 +422,18 @@ __global__ void __launch_bounds__(kW2048 * 64, 3) k_front2048(FrontParams p)
                 issue(ccur, f + 2);
             wave_sync();
 
+            MFX_STAMP2(5);
             // ---- mel filterbank on the frame's 32 lanes: per round every lane walks ONE filter's bins in ascending order,
             // one chain of multiply-adds (mfcccpu.cpp:206-217); weights from the lane's own zero-padded row (16-byte
             // reads), magnitudes as 8-byte reads from even starts spread over the banks by the host
             {
-                float *lmf = lm + (f & 3) * nbp;
+                float *lmf = lm + (f & 3) * lmFS;
                 const float *wrow = s_mw + l * RS;
+#if defined(MFX_ABLATE2048) && (MFX_ABLATE2048 == 1 || MFX_ABLATE2048 == 3)
+                for (int r = 0; r < 0; ++r) { // dev-only ablation: no mel walk
+#else
                 for (int r = 0; r < rounds; ++r) {
+#endif
                     const int st = s_mst[r * 32 + l], fid = s_mfid[r * 32 + l];
                     const int L = p.mel32_L[r];
                     const float *mg = plane + st;
@@ -367,67 +470,58 @@ __global__ void __launch_bounds__(kW2048 * 64, 3) k_front2048(FrontParams p)
                         acc += w1.w * mm[3].y;
                     }
                     wrow += L;
-                    lmf[fid >= 0 ? fid : nbp - 1] = MFX_LOG(fmaxf(acc, 1e-30f)); // idle lane: the row's spare word
+                    lmf[fid >= 0 ? fid : lmFS - 1] = MFX_LOG(fmaxf(acc, 1e-30f)); // idle lane: the spare word
                 }
             }
             wave_sync();
 
+            MFX_STAMP2(6);
             // ---- every 4th frame (and at the chunk's end): DCT-II + lifter of the waiting frames on the matrix pipe,
             // D[row][c] = sum_m A[row][m] B[m][c] with frame g in rows 4g..4g+3, so register 0 of the result is out[g][c]
             // on lane (g, c); tiles of 16 columns, K steps of 4 bands, two accumulator chains (as k_front_reg)
+#if defined(MFX_ABLATE2048) && (MFX_ABLATE2048 == 2 || MFX_ABLATE2048 == 3)
+            if (false) { // dev-only ablation: no DCT, no stores
+#else
             if ((f0 & 2) || last) {
+#endif
                 const int g0 = f0 & ~3, gcount = (n_live - g0) < 4 ? (n_live - g0) : 4;
-                const int gi = lane >> 4, n = lane & 15;
-                float *orow = p.feat + (out_row + g0 + (gi < gcount ? gi : 0)) * (int64_t)p.feat_pitch;
-                if (p.dct_b) {
-                    const float *arow = lm + (n >> 2) * nbp + gi;
-                    const int ks = p.dct_ksteps;
-                    constexpr int TG = 3;
-                    for (int t0 = 0; t0 < p.dct_tiles; t0 += TG) {
-                        const int nt = p.dct_tiles - t0 < TG ? p.dct_tiles - t0 : TG;
-                        const float *bp = p.dct_b + (int64_t)t0 * ks * 64 + lane;
-                        f32x4 d0[TG], d1[TG];
+                if (p.dct_b4) {
+                    const float *arow = lm + (lane & 3) * lmFS;
+                    for (int tile = 0; tile < dct_tiles64; ++tile) {
+                        float res[4];
+                        dct_mfma4(arow, dct_rsrc, dct_bytes, lane, tile, dct_ks, res);
+                        const int col = 64 * tile + lane;
+                        if (col < p.cols) {
 #pragma unroll
-                        for (int tt = 0; tt < TG; ++tt) d0[tt] = d1[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        for (int j0 = 0; j0 < ks; j0 += 8) {
-                            float bv[TG][8], av[8];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) av[u] = arow[j0 + u < ks ? 4 * (j0 + u) : 0];
-#pragma unroll
-                            for (int tt = 0; tt < TG; ++tt)
-#pragma unroll
-                                for (int u = 0; u < 8; ++u)
-                                    bv[tt][u] = (tt < nt && j0 + u < ks) ? bp[((int64_t)tt * ks + j0 + u) * 64] : 0.f;
-#pragma unroll
-                            for (int tt = 0; tt < TG; ++tt) {
-                                if (tt >= nt) break;
-#pragma unroll
-                                for (int u = 0; u < 8; u += 2) {
-                                    d0[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[tt][u], d0[tt], 0, 0, 0);
-                                    d1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[tt][u + 1], d1[tt], 0, 0, 0);
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int tt = 0; tt < TG; ++tt) {
-                            const int col = 16 * (t0 + tt) + n;
-                            if (tt < nt && gi < gcount && col < p.cols) orow[col] = d0[tt][0] + d1[tt][0];
+                            for (int i = 0; i < 4; ++i)
+                                if (i < gcount) (p.feat + (out_row + g0 + i) * (int64_t)p.feat_pitch)[col] = res[i];
                         }
                     }
                 } else { // no DCT: the log mel energies are the features
                     for (int g = 0; g < gcount; ++g)
                         for (int cc = lane; cc < p.cols; cc += 64)
-                            (p.feat + (out_row + g0 + g) * (int64_t)p.feat_pitch)[cc] = lm[g * nbp + cc];
+                            (p.feat + (out_row + g0 + g) * (int64_t)p.feat_pitch)[cc] = lm[g * lmFS + cc];
                 }
                 wave_sync();
             }
+            MFX_STAMP2(7);
         }
         if (n_live <= 0) issue(cnxt, half); // empty chunk: its last iteration never ran, nothing was requested
         c_cur = c_nxt;
         ccur = cnxt;
         c_nxt = draw();
         cnxt = make_ctx(c_nxt);
+        MFX_STAMP2(8);
     }
+#ifdef MFX_STAMPS
+    if (lane == 0 && p.spec) {
+        unsigned long long *o = (unsigned long long *)p.spec + (size_t)(blockIdx.x * n_waves + wave) * 10;
+        unsigned long long st_rt1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1)::"memory");
+        st_acc[9] = st_rt1 - st_rt0; // 100 MHz ticks over the same span
+        for (int i = 0; i < 10; ++i) o[i] = st_acc[i];
+    }
+#endif
 }
 
 } // namespace
@@ -439,10 +533,11 @@ bool front2048_supported(int fft_size, int window_size, int num_banks, int cols,
 }
 
 namespace {
+int lm_fs(const FrontParams &p) { return lm_fs4(p.num_banks); }
 size_t lds_bytes_2048(const FrontParams &p, int n_waves)
 {
     const size_t f = front2048_table_floats(p.mel32_rounds, p.mel32_row_stride) +
-                     (size_t)n_waves * (2 * kPlane + 4 * lm_stride(p.num_banks)) + 4;
+                     (size_t)n_waves * (2 * kPlane + 4 * (size_t)lm_fs(p)) + 4;
     return f * sizeof(float);
 }
 // waves per block (one block per CU): as many of 12 as the CU's 160 KB of LDS hold, at least 6 (0: does not fit)

@@ -101,6 +101,7 @@ struct FrontParams {
     int32_t mel32_L[8];
     // DCT on the matrix pipe: B operands [dct_tiles][dct_ksteps][64] (build_dct_mfma_operands), read from L1 / L2
     const float *dct_b;
+    const float *dct_b4;          // 4x4x1 form: [ceil(dct_len / 64)][dct_ksteps][64][4] (k_front2048, build_dct_mfma_operands4)
     int32_t dct_tiles, dct_ksteps;
     int32_t num_banks;
     int32_t dct_len;

@@ -246,6 +246,19 @@ void build_dct_mfma_operands(const std::vector<float> &dct, int num_banks, int d
             }
 }
 
+void build_dct_mfma_operands4(const std::vector<float> &dct, int num_banks, int dct_len, std::vector<float> &out)
+{
+    const int tiles = (dct_len + 63) / 64, ks = (num_banks + 3) / 4;
+    out.assign((size_t)tiles * ks * 64 * 4, 0.0f);
+    for (int tl = 0; tl < tiles; ++tl)
+        for (int j4 = 0; j4 < ks; ++j4)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int u = 0; u < 4; ++u) {
+                    const int m = 4 * j4 + u, c = 64 * tl + lane;
+                    if (m < num_banks && c < dct_len) out[(((size_t)tl * ks + j4) * 64 + lane) * 4 + u] = dct[(size_t)m * dct_len + c];
+                }
+}
+
 void build_dct_transposed(const std::vector<float> &dct, int num_banks, int dct_len, int &stride, int &nb_pad,
                           std::vector<float> &out)
 {

@@ -83,6 +83,10 @@ bool build_mel_wave_plan(const MelTable &t, int num_banks, int fft_size, int max
 void build_dct_mfma_operands(const std::vector<float> &dct, int num_banks, int dct_len, int &tiles, int &ksteps,
                              std::vector<float> &out);
 
+// B operands of the DCT on v_mfma_f32_4x4x1_16b_f32 (k_front2048): 64 output columns per tile, four bands per 16-byte load,
+// out[((tile * ks + j4) * 64 + lane) * 4 + u] = dct[4 j4 + u][64 tile + lane], ks = ceil(num_banks / 4), zero beyond the matrix.
+void build_dct_mfma_operands4(const std::vector<float> &dct, int num_banks, int dct_len, std::vector<float> &out);
+
 // Transposed, padded DCT matrix for the 512-point kernel: [cols][stride], stride / 4 odd,
 // row c = column c of the [num_banks][dct_len] matrix followed by zeros.
 void build_dct_transposed(const std::vector<float> &dct, int num_banks, int dct_len, int &stride, int &nb_pad,

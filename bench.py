@@ -293,6 +293,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="strong: one job of the workload's n_utt_total utterances sharded round-robin over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--engine", type=int, default=0, help="mfx_config.engine bits (A/B of equivalent kernels; 0 = the library's choice)")
+    ap.add_argument("--tail-split", type=int, default=0, help="mfx_config.tail_split (0 = default, -1 = off)")
     ap.add_argument("--overlap", action="store_true",
                     help="let the delta tail of a step overlap the next step's front end (mfx_batch_overlap); measured "
                          "neutral on MI355X -- the front end's waves fill the register file -- so off by default")
@@ -334,7 +336,7 @@ def main():
     channels = wl.get("channels", 1)
     m = pkg.MfccHip(wl["utt_samples"] + 1000, W, S, wl["nb"], wl["sr"], 64.0, wl["sr"] / 2, wl["nc"], bool(wl.get("c0")),
                     22.0, wl.get("norm", pkg.NORM_NONE), wl["dyn"], 3, 3, True, device=dev_index, fft_size=wl["fft"],
-                    channels=channels)
+                    channels=channels, engine=args.engine, tail_split=args.tail_split)
     m.set_window(window)
     strong = args.scaling == "strong"
     if strong and "n_utt_total" not in wl:

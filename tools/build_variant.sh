@@ -13,6 +13,13 @@ if [ -n "$REV" ]; then
   SRC=/tmp/var_$NAME/mfx_kernels.hip
 fi
 /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize $DEFS -I$C -c $SRC -o /tmp/var_$NAME/k.o
+# F2048_REV=<git-rev>: k_front2048's source taken from that commit (the current headers must still fit it)
+SRC2=$C/mfx_front2048.hip
+if [ -n "${F2048_REV:-}" ]; then
+  git -C $R show $F2048_REV:asr-featext-opencl_amd/csrc/mfx_front2048.hip > /tmp/var_$NAME/mfx_front2048.hip
+  SRC2=/tmp/var_$NAME/mfx_front2048.hip
+fi
+/opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize $DEFS -I$C -c $SRC2 -o /tmp/var_$NAME/k2.o
 make -s -C $C mfx_api.o mfx_tables.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $R/build/var/lib_$NAME.so /tmp/var_$NAME/k.o $C/mfx_api.o $C/mfx_tables.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $R/build/var/lib_$NAME.so /tmp/var_$NAME/k.o /tmp/var_$NAME/k2.o $C/mfx_api.o $C/mfx_tables.o
 echo built build/var/lib_$NAME.so
