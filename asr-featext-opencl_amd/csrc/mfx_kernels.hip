@@ -168,6 +168,18 @@ constexpr int kSplitStride = 20; // dwords per lane row of the split-twiddle tab
 // DCT on the matrix pipe (dct_mode 1): K steps of v_mfma_f32_16x16x4_f32 over the mel bands, 4 bands per step
 constexpr int kDctSteps = 10;  // num_banks <= 40
 constexpr int kDctRow = 12;    // dwords per lane row of the B operand table in LDS (16-byte words, disjoint bank quads)
+// MFX_DCT_QUARTERS (default): the same DCT as 10 v_mfma_f32_4x4x1_16b_f32 -- 16 independent 4 x 4 outer products per
+// instruction: block (kb = lane >> 4, cg = (lane >> 2) & 3) accumulates frames i = 0..3 x columns 4 cg + j over the bands
+// 10 kb .. 10 kb + 9, one band per instruction; the four band quarters are then added across the 16-lane rows
+// (v_permlane16_swap / v_permlane32_swap).  On gfx950 f32 matrix instructions run on the vector pipe's FP32 units
+// (SQ_VALU_MFMA_COEXEC_CYCLES = 0), so their cycles are the SIMD's cycles: 10 x 8 here against 10 x 32 for the
+// 16 x 16 x 4 form, which used a quarter of its rows (4 frames).
+#ifndef MFX_DCT_QUARTERS
+#define MFX_DCT_QUARTERS 1
+#endif
+constexpr int kDctQ = 10;      // bands per quarter
+constexpr int kDctQPad = 12;   // floats per quarter in the frame's log-energy row (16-byte aligned quarters)
+__device__ __forceinline__ int dct_q_pos(int m) { return kDctQPad * (m / kDctQ) + (m % kDctQ); }
 
 // Partner fetch of the real split: lanes l >= 1 get x[16 - l] (mirror, then shift right by one inside the row);
 // lane 0, which the shift leaves without a source, keeps `own` -- its partner lives in its own registers.
@@ -511,12 +523,18 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
         for (int i = tid; i < 16 * rounds; i += kThreads) {
             s_mmeta[2 * i] = p.mel_lane_start[i];
             const int fid = p.mel_lane_fid[i];
-            s_mmeta[2 * i + 1] = (fid < 0 && p.dct_mode == 1) ? 4 * kDctSteps : fid; // (matrix-pipe form: idle lanes park their value in a word nobody reads)
+            // (matrix-pipe form: idle lanes park their value in a word nobody reads)
+            if (MFX_DCT_QUARTERS)
+                s_mmeta[2 * i + 1] = p.dct_mode != 1 ? fid : fid < 0 ? 4 * kDctQPad : dct_q_pos(fid);
+            else
+                s_mmeta[2 * i + 1] = (fid < 0 && p.dct_mode == 1) ? 4 * kDctSteps : fid;
         }
         if (p.dct_mode == 1) {
             // B operand of K step j on lane (k = lane >> 4, n = lane & 15) is dct[4 j + k][n]; zeros beyond the matrix
             for (int i = tid; i < 64 * kDctRow; i += kThreads) {
-                const int ln = i / kDctRow, j = i - ln * kDctRow, m = 4 * j + (ln >> 4), n = ln & 15;
+                // (MFX_DCT_QUARTERS: B operand of band 10 kb + j on lane (kb = lane >> 4, n = lane & 15))
+                const int ln = i / kDctRow, j = i - ln * kDctRow, n = ln & 15;
+                const int m = MFX_DCT_QUARTERS ? kDctQ * (ln >> 4) + j : 4 * j + (ln >> 4);
                 s_dct[i] = (j < kDctSteps && m < p.num_banks && n < p.dct_len) ? p.dct[m * p.dct_len + n] : 0.f;
             }
         } else {
@@ -871,6 +889,35 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
                         lm[fid] = MFX_LOG(fmaxf(acc, 1e-30f)); // (idle lanes: fid names a word nobody reads)
                     }
                     wave_sync();
+#if MFX_DCT_QUARTERS
+                    // A operand of lane (kb = lane >> 4, i = lane & 3): frame i's log energies of bands 10 kb + t (the row of
+                    // slot i, quarter kb: 12 floats, 16-byte aligned); B operand: this lane's 10 coefficients.  Two accumulator
+                    // chains (even / odd bands of the quarter), each ascending in m.
+                    const float4 *aq = (const float4 *)(s_wave + (lane & 3) * (kSlot + 8) + kMelOff + kDctQPad * slot);
+                    const float4 *bq = (const float4 *)(s_dct + lane * kDctRow);
+                    const float4 a0 = aq[0], a1 = aq[1], a2 = aq[2];
+                    const float4 dq0 = bq[0], dq1 = bq[1], dq2 = bq[2];
+                    f32x4 dacc = {0.f, 0.f, 0.f, 0.f}, dacc2 = {0.f, 0.f, 0.f, 0.f};
+                    dacc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, dq0.x, dacc, 0, 0, 0);
+                    dacc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, dq0.y, dacc2, 0, 0, 0);
+                    dacc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, dq0.z, dacc, 0, 0, 0);
+                    dacc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, dq0.w, dacc2, 0, 0, 0);
+                    dacc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, dq1.x, dacc, 0, 0, 0);
+                    dacc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, dq1.y, dacc2, 0, 0, 0);
+                    dacc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, dq1.z, dacc, 0, 0, 0);
+                    dacc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, dq1.w, dacc2, 0, 0, 0);
+                    dacc = __builtin_amdgcn_mfma_f32_4x4x1f32(a2.x, dq2.x, dacc, 0, 0, 0);
+                    dacc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a2.y, dq2.y, dacc2, 0, 0, 0);
+                    // register i of lane (kb, c) now holds frame i's partial sum of column c over quarter kb; the lane that
+                    // stores out[slot][l] is (row slot, column l): add the quarters across the four 16-lane rows while moving
+                    // frame i's sums to row i (two butterfly steps: rows 1 <-> 0 / 3 <-> 2, then the two halves of the wave)
+                    const auto r01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(dacc[0] + dacc2[0]), __float_as_uint(dacc[1] + dacc2[1]), false, false);
+                    const auto r23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(dacc[2] + dacc2[2]), __float_as_uint(dacc[3] + dacc2[3]), false, false);
+                    const float s01 = __uint_as_float(r01[0]) + __uint_as_float(r01[1]);
+                    const float s23 = __uint_as_float(r23[0]) + __uint_as_float(r23[1]);
+                    const auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
+                    const float outv = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
+#else
                     const float *arow = s_wave + (l >> 2) * (kSlot + 8) + kMelOff + slot; // A[row l][k = slot] of K step 0
                     const float4 *bq = (const float4 *)(s_dct + lane * kDctRow);
                     const float4 dq0 = bq[0], dq1 = bq[1], dq2 = bq[2];
@@ -884,6 +931,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
                         dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * j + 4], dctb[j + 1], dacc2, 0, 0, 0);
                     }
                     const float outv = dacc[0] + dacc2[0];
+#endif
                     // pitch 16 = compact static scratch: write whole 64-byte rows (zeros beyond cols)
                     if (live && (l < cols || p.feat_pitch == 16)) dst[l] = outv;
                 } else {
