@@ -1076,7 +1076,9 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
         s_mmeta[2 * i + 1] = fid < 0 ? 4 * kDctStepsL : fid; // idle lanes park their value in a word nobody reads
     }
     for (int i = tid; i < 64 * kDctRowL; i += kWavesL * 64) {
-        const int ln = i / kDctRowL, j = i - ln * kDctRowL, m = 4 * j + (ln >> 4), n = ln & 15;
+        // (MFX_DCT_QUARTERS: B operand of band 20 kb + j on lane (kb = lane >> 4, n = lane & 15); see k_front512)
+        const int ln = i / kDctRowL, j = i - ln * kDctRowL, n = ln & 15;
+        const int m = MFX_DCT_QUARTERS ? kDctStepsL * (ln >> 4) + j : 4 * j + (ln >> 4);
         s_dct[i] = (m < p.num_banks && n < p.dct_len) ? p.dct[m * p.dct_len + n] : 0.f;
     }
     for (int i = lane; i < 4 * kSlotL; i += 64) s_wave[i] = 0.f; // words read before they are written meet zero weights: finite
@@ -1342,6 +1344,32 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
             wave_sync();
             // ---- DCT-II + lifter on the matrix pipe (see k_front512): frame `slot` in rows 4 slot .. 4 slot + 3
             {
+#if MFX_DCT_QUARTERS
+                // 20 v_mfma_f32_4x4x1_16b_f32 over band quarters (20 bands each: the frame's row holds them back to back,
+                // 80-byte quarters), then the cross-row butterfly -- see k_front512
+                const float4 *aq = (const float4 *)(s_wave + (lane & 3) * (kSlotL + 8) + kMelOffL + kDctStepsL * slot);
+                const float4 *bq = (const float4 *)(s_dct + lane * kDctRowL);
+                f32x4 dacc = {0.f, 0.f, 0.f, 0.f}, dacc2 = {0.f, 0.f, 0.f, 0.f};
+                float4 av[kDctStepsL / 4], bv[kDctStepsL / 4];
+#pragma unroll
+                for (int j = 0; j < kDctStepsL / 4; ++j) {
+                    av[j] = aq[j];
+                    bv[j] = bq[j];
+                }
+#pragma unroll
+                for (int j = 0; j < kDctStepsL / 4; ++j) {
+                    dacc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j].x, bv[j].x, dacc, 0, 0, 0);
+                    dacc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j].y, bv[j].y, dacc2, 0, 0, 0);
+                    dacc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j].z, bv[j].z, dacc, 0, 0, 0);
+                    dacc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j].w, bv[j].w, dacc2, 0, 0, 0);
+                }
+                const auto r01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(dacc[0] + dacc2[0]), __float_as_uint(dacc[1] + dacc2[1]), false, false);
+                const auto r23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(dacc[2] + dacc2[2]), __float_as_uint(dacc[3] + dacc2[3]), false, false);
+                const float s01 = __uint_as_float(r01[0]) + __uint_as_float(r01[1]);
+                const float s23 = __uint_as_float(r23[0]) + __uint_as_float(r23[1]);
+                const auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
+                const float outv = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
+#else
                 const float *arow = s_wave + (l >> 2) * (kSlotL + 8) + kMelOffL + slot;
                 const float4 *bq = (const float4 *)(s_dct + lane * kDctRowL);
                 float dctb[kDctStepsL];
@@ -1360,6 +1388,7 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
                     dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * j + 4], dctb[j + 1], dacc2, 0, 0, 0);
                 }
                 const float outv = dacc[0] + dacc2[0];
+#endif
                 if (live && (l < cols || p.feat_pitch == 16)) dst[l] = outv;
             }
             wave_sync();
