@@ -25,7 +25,6 @@ from .mfcc import (  # noqa: F401
     host_dct_matrix,
     host_dct_mfma_operands,
     host_frame_count,
-    host_mel_item_plan,
     host_mel_lane_plan,
     host_mel_table,
     library_path,

@@ -72,9 +72,12 @@ struct mfx_handle {
     // tables in HBM
     DevBuf<float> d_win1024o;
     DevBuf<float> d_window, d_winpair, d_twid_pass, d_twid_half, d_twid_split, d_twid_reg, d_mel_w, d_dct;
-    DevBuf<int32_t> d_mel_beg, d_mel_items, d_mel_pieces;
-    DevBuf<float> d_mel_item_w, d_sweep_item_w;
-    int mel_K = 0, mel_wlen = 0, sweep_wlen = 0;
+    DevBuf<int32_t> d_mel_beg;
+    DevBuf<int32_t> d_mel64_L;                       // [8] of the handle's own plan (k_melcep reads L from memory)
+    // VTLN sweep: one 64-lane plan per alpha, padded to a common row stride
+    DevBuf<float> d_sweep64_w;
+    DevBuf<int32_t> d_sweep64_start, d_sweep64_fid, d_sweep64_L;
+    int sweep64_rs = 0;
     // 512-point kernel: per-lane mel plan + transposed DCT matrix
     DevBuf<float> d_mel_lane_w, d_dct_t;
     DevBuf<int32_t> d_mel_lane_start, d_mel_lane_fid;
@@ -116,8 +119,7 @@ struct mfx_handle {
     int sweep_cap = 0;                    // alphas the sweep buffers hold
     int sweep_n = 0;                      // alphas of the last sweep (0: last apply was a plain one)
     DevBuf<float> d_sweep_w, d_sweep_src, d_sweep_blk, d_sweep_stats;
-    DevBuf<int32_t> d_sweep_beg, d_sweep_items, d_sweep_pieces;
-    int sweep_K = 0;
+    DevBuf<int32_t> d_sweep_beg;
     DevBuf<Segment> d_sweep_segs;         // [2][sweep_cap]: rows with context, rows delivered
 
     // batch plan
@@ -205,15 +207,6 @@ int refresh_mel(mfx_handle *h)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, upload(h->d_mel_w, t.weights));
     HIP_TRY(h, upload(h->d_mel_beg, t.beg));
-    {
-        MelItemPlan ip;
-        build_mel_item_plan(t, h->nb, h->W2, ip);
-        HIP_TRY(h, upload(h->d_mel_items, ip.items));
-        HIP_TRY(h, upload(h->d_mel_pieces, ip.pieces));
-        HIP_TRY(h, upload(h->d_mel_item_w, ip.w));
-        h->mel_K = ip.K;
-        h->mel_wlen = (int)ip.w.size();
-    }
     h->fused_ok = false;
     if (h->fast512 && build_mel_lane_plan(t, h->nb, h->W2, /*max_read_bin=*/511 - 32, h->plan)) {
         HIP_TRY(h, upload(h->d_mel_lane_w, h->plan.w));
@@ -235,16 +228,20 @@ int refresh_mel(mfx_handle *h)
             h->fused_ok = front1024_lds_bytes(probe) <= 160 * 1024;
         }
     }
+    // The 64-lane plan (whole filters walked on a wave's lanes): k_front_reg / k_front_wave fused, and k_melcep -- the
+    // streaming apply(), sweeps and the spectrum path of the batch entry, i.e. EVERY configuration needs it.  The kernels'
+    // magnitude buffers hold W2 floats (bins 0 .. W2/2, finite words beyond).
     h->wplan_ok = false;
-    if (h->W2 >= 1024 && h->W2 <= 2048) { // the fused long-transform kernel walks the filters on the frame's 64 lanes
-        const int M = h->W2 / 2, MP = M; // floats of the wave's complex buffer = 2 MP (k_front_reg)
-        if (build_mel_wave_plan(t, h->nb, h->W2, /*max_read_bin=*/2 * MP - 1, h->wplan)) {
-            HIP_TRY(h, upload(h->d_mel64_w, h->wplan.w));
-            HIP_TRY(h, upload(h->d_mel64_start, h->wplan.start));
-            HIP_TRY(h, upload(h->d_mel64_fid, h->wplan.fid));
-            h->wplan_ok = true;
-        }
+    if (!build_mel_wave_plan(t, h->nb, h->W2, /*max_read_bin=*/h->W2 - 1, h->wplan))
+        return fail(h, MFX_ERR_CONFIG, "mel filterbank does not fit the kernels' lane plan (more than 512 filters?)");
+    HIP_TRY(h, upload(h->d_mel64_w, h->wplan.w));
+    HIP_TRY(h, upload(h->d_mel64_start, h->wplan.start));
+    HIP_TRY(h, upload(h->d_mel64_fid, h->wplan.fid));
+    {
+        std::vector<int32_t> L(h->wplan.L, h->wplan.L + 8);
+        HIP_TRY(h, upload(h->d_mel64_L, L));
     }
+    h->wplan_ok = true;
     h->wplan32_ok = false;
     if (h->fast2048) { // k_front2048 walks the filters on the 32 lanes of each of a wave's two frames
         if (build_mel_wave_plan(t, h->nb, h->W2, /*max_read_bin=*/1039, h->wplan32, /*lanes=*/32)) {
@@ -281,11 +278,6 @@ void fill_front(const mfx_handle *h, FrontParams &p)
     p.twid_split = h->d_twid_split.p;
     p.mel_w = h->d_mel_w.p;
     p.mel_beg = h->d_mel_beg.p;
-    p.mel_items = h->d_mel_items.p;
-    p.mel_pieces = h->d_mel_pieces.p;
-    p.mel_item_w = h->d_mel_item_w.p;
-    p.mel_K = h->mel_K;
-    p.mel_wlen = h->mel_wlen;
     p.dct = h->ceps > 0 ? h->d_dct.p : nullptr;
     p.num_banks = h->nb;
     p.dct_len = h->dl;
@@ -433,12 +425,11 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_mel_w.release();
     h->d_dct.release();
     h->d_mel_beg.release();
-    h->d_mel_items.release();
-    h->d_mel_item_w.release();
-    h->d_sweep_item_w.release();
-    h->d_mel_pieces.release();
-    h->d_sweep_items.release();
-    h->d_sweep_pieces.release();
+    h->d_mel64_L.release();
+    h->d_sweep64_w.release();
+    h->d_sweep64_start.release();
+    h->d_sweep64_fid.release();
+    h->d_sweep64_L.release();
     h->d_mel_lane_w.release();
     h->d_mel64_w.release();
     h->d_mel64_start.release();
@@ -630,10 +621,8 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
                 std::vector<float> ob;
                 build_dct_mfma_operands(m, h->nb, h->dl, h->dct_tiles, h->dct_ksteps, ob);
                 if (upload(h->d_dct_b, ob) != hipSuccess) return bail(MFX_ERR_DEVICE);
-                if (h->fast2048) {
-                    build_dct_mfma_operands4(m, h->nb, h->dl, ob);
-                    if (upload(h->d_dct_b4, ob) != hipSuccess) return bail(MFX_ERR_DEVICE);
-                }
+                build_dct_mfma_operands4(m, h->nb, h->dl, ob); // the 4x4x1 form: k_front2048, k_front_wave, k_melcep
+                if (upload(h->d_dct_b4, ob) != hipSuccess) return bail(MFX_ERR_DEVICE);
             }
             if (h->fast512) {
                 std::vector<float> mt;
@@ -1078,9 +1067,8 @@ int prepare_sweep(mfx_handle *h, const float *alphas, int n)
     if (same && n <= h->sweep_cap && !h->sweep_alphas.empty()) return MFX_OK;
     std::vector<float> w(wstride * n);
     std::vector<int32_t> b(bstride * n);
-    std::vector<MelItemPlan> plans((size_t)n);
-    int K = 1;
-    size_t wlen = 8;
+    std::vector<MelWavePlan> plans((size_t)n);
+    int rs = 4;
     for (int a = 0; a < n; ++a) {
         MelTable t;
         build_mel_table(h->nb, h->W2, h->cfg.sample_rate, h->cfg.low_freq, h->cfg.high_freq, alphas[a], t);
@@ -1088,30 +1076,59 @@ int prepare_sweep(mfx_handle *h, const float *alphas, int n)
             if (v < 0 || v > h->W2 / 2) return fail(h, MFX_ERR_CONFIG, "mel filter edge outside [0, fft_size/2]");
         std::copy(t.weights.begin(), t.weights.end(), w.begin() + wstride * a);
         std::copy(t.beg.begin(), t.beg.end(), b.begin() + bstride * a);
-        build_mel_item_plan(t, h->nb, h->W2, plans[a]);
-        K = std::max(K, plans[a].K);
-        wlen = std::max(wlen, plans[a].w.size());
+        if (!build_mel_wave_plan(t, h->nb, h->W2, /*max_read_bin=*/h->W2 - 1, plans[a]))
+            return fail(h, MFX_ERR_CONFIG, "mel filterbank does not fit the kernels' lane plan");
+        rs = std::max(rs, plans[a].row_stride);
     }
-    // one item table per alpha, all padded to the longest plan (idle entries have slot -1)
-    std::vector<int32_t> items((size_t)n * K * 256, 0), pieces((size_t)n * h->nb);
-    std::vector<float> item_w((size_t)n * wlen, 0.f);
+    // one 64-lane plan per alpha, the weight rows padded to the longest plan's stride (a row's rounds lie back to back from
+    // its start, so padding at the end changes nothing)
+    const int rounds = plans[0].rounds;
+    std::vector<float> pw((size_t)n * 64 * rs, 0.f);
+    std::vector<int32_t> pst((size_t)n * 64 * rounds), pfid((size_t)n * 64 * rounds), pL((size_t)n * 8);
     for (int a = 0; a < n; ++a) {
-        int32_t *dst = &items[(size_t)a * K * 256];
-        for (int i = 0; i < K * 64; ++i) dst[4 * i] = -1;
-        std::copy(plans[a].items.begin(), plans[a].items.end(), dst);
-        std::copy(plans[a].pieces.begin(), plans[a].pieces.end(), pieces.begin() + (size_t)a * h->nb);
-        std::copy(plans[a].w.begin(), plans[a].w.end(), item_w.begin() + (size_t)a * wlen);
+        for (int j = 0; j < 64; ++j)
+            std::copy(plans[a].w.begin() + (size_t)j * plans[a].row_stride, plans[a].w.begin() + (size_t)(j + 1) * plans[a].row_stride,
+                      pw.begin() + ((size_t)a * 64 + j) * rs);
+        std::copy(plans[a].start.begin(), plans[a].start.end(), pst.begin() + (size_t)a * 64 * rounds);
+        std::copy(plans[a].fid.begin(), plans[a].fid.end(), pfid.begin() + (size_t)a * 64 * rounds);
+        std::copy(plans[a].L, plans[a].L + 8, pL.begin() + (size_t)a * 8);
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(h->d_sweep_w.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_sweep_beg.p, b.data(), b.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(h, upload(h->d_sweep_items, items));
-    HIP_TRY(h, upload(h->d_sweep_pieces, pieces));
-    HIP_TRY(h, upload(h->d_sweep_item_w, item_w));
-    h->sweep_K = K;
-    h->sweep_wlen = (int)wlen;
+    HIP_TRY(h, upload(h->d_sweep64_w, pw));
+    HIP_TRY(h, upload(h->d_sweep64_start, pst));
+    HIP_TRY(h, upload(h->d_sweep64_fid, pfid));
+    HIP_TRY(h, upload(h->d_sweep64_L, pL));
+    h->sweep64_rs = rs;
     h->sweep_alphas.assign(alphas, alphas + n);
     return MFX_OK;
+}
+
+// k_melcep parameters that do not depend on the caller: the handle's own filterbank (sweep = false) or the sweep's tables
+void fill_melcep(const mfx_handle *h, MelcepParams &mp, bool sweep)
+{
+    std::memset(&mp, 0, sizeof(mp));
+    mp.spec_pitch = h->spec_pitch;
+    mp.fft_size = h->W2;
+    mp.mel_w = sweep ? h->d_sweep_w.p : h->d_mel_w.p;
+    mp.mel_beg = sweep ? h->d_sweep_beg.p : h->d_mel_beg.p;
+    mp.mel64_w = sweep ? h->d_sweep64_w.p : h->d_mel64_w.p;
+    mp.mel64_start = sweep ? h->d_sweep64_start.p : h->d_mel64_start.p;
+    mp.mel64_fid = sweep ? h->d_sweep64_fid.p : h->d_mel64_fid.p;
+    mp.mel64_L = sweep ? h->d_sweep64_L.p : h->d_mel64_L.p;
+    mp.mel64_rounds = h->wplan.rounds;
+    mp.mel64_row_stride = sweep ? h->sweep64_rs : h->wplan.row_stride;
+    mp.mag_floats = std::max(h->W2, (h->spec_pitch + 3) & ~3);
+    mp.dct = h->ceps > 0 ? h->d_dct.p : nullptr;
+    mp.dct_b4 = h->ceps > 0 ? h->d_dct_b4.p : nullptr;
+    mp.dct_ksteps = h->dct_ksteps;
+    mp.num_banks = h->nb;
+    mp.dct_len = h->dl;
+    mp.cols = h->cols;
+    mp.n_tables = 1;
+    mp.mel_w_stride = (int64_t)2 * h->W2;
+    mp.mel_beg_stride = h->nb + 2;
 }
 
 // apply() for the current block: n_alpha == 0 -> the handle's alpha into d_src/d_blk (ParamBase::apply);
@@ -1152,30 +1169,12 @@ int apply_impl(mfx_handle *h, const float *alphas, int n_alpha)
 
     // filterbank + log + DCT over all frames with context
     MelcepParams mp;
-    std::memset(&mp, 0, sizeof(mp));
+    fill_melcep(h, mp, sweep);
     mp.spec = h->d_spec.p;
-    mp.spec_pitch = h->spec_pitch;
     mp.n_rows = wcnd;
     mp.feat = d_src;
     mp.feat_pitch = h->cols;
-    mp.fft_size = h->W2;
-    mp.mel_w = sweep ? h->d_sweep_w.p : h->d_mel_w.p;
-    mp.mel_beg = sweep ? h->d_sweep_beg.p : h->d_mel_beg.p;
-    mp.mel_items = sweep ? h->d_sweep_items.p : h->d_mel_items.p;
-    mp.mel_pieces = sweep ? h->d_sweep_pieces.p : h->d_mel_pieces.p;
-    mp.mel_item_w = sweep ? h->d_sweep_item_w.p : h->d_mel_item_w.p;
-    mp.mel_K = sweep ? h->sweep_K : h->mel_K;
-    mp.mel_wlen = sweep ? h->sweep_wlen : h->mel_wlen;
-    mp.mel_items_stride = mp.mel_K * 256;
-    mp.mel_pieces_stride = h->nb;
-    mp.mel_item_w_stride = mp.mel_wlen;
-    mp.dct = h->ceps > 0 ? h->d_dct.p : nullptr;
-    mp.num_banks = h->nb;
-    mp.dct_len = h->dl;
-    mp.cols = h->cols;
     mp.n_tables = n_tab;
-    mp.mel_w_stride = (int64_t)2 * h->W2;
-    mp.mel_beg_stride = h->nb + 2;
     mp.feat_table_stride = (int64_t)h->cap_rows * h->cols;
     HIP_TRY(h, launch_melcep(mp, h->stream));
 
@@ -1603,7 +1602,7 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
     // points; at 4096 points the tables + per-wave buffers no longer leave enough waves per CU)
     // (2048 points, window <= 1152 samples: two frames per wave; mono needs aligned sample pairs)
     const bool fused2048 = h->fast2048 && h->wplan32_ok && (h->channels == 2 || p.pair_ok);
-    const bool fusedgen = !fused512 && !fused1024 && !fused2048 && h->W2 <= 2048 && (h->W2 < 1024 || h->wplan_ok) &&
+    const bool fusedgen = !fused512 && !fused1024 && !fused2048 && h->W2 <= 2048 && h->wplan_ok &&
                           front_wave_lds_bytes(p, true) <= 160 * 1024;
     // With deltas on, the front end writes its statics as compact 64-byte rows into a scratch buffer
     // and the delta kernel emits whole [static | d | dd] rows: every HBM write is then a full line
@@ -1688,24 +1687,11 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
                     HIP_TRY(h, launch_front_generic(q, /*fused=*/false, h->stream));
             }
             MelcepParams mp;
-            std::memset(&mp, 0, sizeof(mp));
+            fill_melcep(h, mp, false);
             mp.spec = h->d_spec_slab.p;
-            mp.spec_pitch = h->spec_pitch;
             mp.n_rows = rows;
             mp.feat = p.feat + row0 * (int64_t)p.feat_pitch;
             mp.feat_pitch = p.feat_pitch;
-            mp.fft_size = h->W2;
-            mp.mel_w = h->d_mel_w.p;
-            mp.mel_beg = h->d_mel_beg.p;
-            mp.mel_items = h->d_mel_items.p;
-            mp.mel_pieces = h->d_mel_pieces.p;
-            mp.mel_item_w = h->d_mel_item_w.p;
-            mp.mel_K = h->mel_K;
-            mp.mel_wlen = h->mel_wlen;
-            mp.dct = h->ceps > 0 ? h->d_dct.p : nullptr;
-            mp.num_banks = h->nb;
-            mp.dct_len = h->dl;
-            mp.cols = h->cols;
             HIP_TRY(h, launch_melcep(mp, h->stream));
             c0 = c1;
         }
@@ -1931,28 +1917,6 @@ extern "C" int mfx_host_mel_table(int32_t num_banks, int32_t fft_size, float sam
     return MFX_OK;
 }
 
-extern "C" int mfx_host_mel_item_plan(int32_t num_banks, int32_t fft_size, const float *weights, const int32_t *beg,
-                                      int32_t *items, int64_t items_cap, int32_t *pieces, float *w, int64_t w_cap,
-                                      int64_t *w_len)
-{
-    if (num_banks <= 0 || fft_size <= 0 || !weights || !beg) return MFX_ERR_ARG;
-    MelTable t;
-    t.weights.assign(weights, weights + (size_t)2 * fft_size);
-    t.beg.assign(beg, beg + num_banks + 2);
-    for (int v : t.beg)
-        if (v < 0 || v > fft_size / 2) return MFX_ERR_ARG;
-    MelItemPlan plan;
-    build_mel_item_plan(t, num_banks, fft_size, plan);
-    if (w_len) *w_len = (int64_t)plan.w.size();
-    if (items) {
-        if ((int64_t)plan.items.size() > items_cap || (w && (int64_t)plan.w.size() > w_cap)) return MFX_ERR_ARG;
-        std::memcpy(items, plan.items.data(), sizeof(int32_t) * plan.items.size());
-        if (w) std::memcpy(w, plan.w.data(), sizeof(float) * plan.w.size());
-    }
-    if (pieces) std::memcpy(pieces, plan.pieces.data(), sizeof(int32_t) * plan.pieces.size());
-    return plan.K;
-}
-
 // Lane plan of the mel walk (lanes = 16: the 512-point kernel's MelLanePlan, max_read_bin 479; lanes = 64: the
 // long-transform kernel's MelWavePlan).  Returns the number of rounds (<= 8), or an error.  Outputs (any may be NULL to
 // query): L[8] bins per lane and round, *row_stride, start / fid [rounds][lanes], w [lanes][row_stride].
@@ -1960,7 +1924,7 @@ extern "C" int mfx_host_mel_lane_plan(int32_t lanes, int32_t num_banks, int32_t 
                                       const int32_t *beg, int32_t max_read_bin, int32_t *L, int32_t *row_stride,
                                       int32_t *start, int32_t *fid, float *w, int64_t w_cap)
 {
-    if ((lanes != 16 && lanes != 64) || num_banks <= 0 || fft_size <= 0 || !weights || !beg) return MFX_ERR_ARG;
+    if ((lanes != 16 && lanes != 32 && lanes != 64) || num_banks <= 0 || fft_size <= 0 || !weights || !beg) return MFX_ERR_ARG;
     MelTable t;
     t.weights.assign(weights, weights + (size_t)2 * fft_size);
     t.beg.assign(beg, beg + num_banks + 2);
@@ -1977,7 +1941,7 @@ extern "C" int mfx_host_mel_lane_plan(int32_t lanes, int32_t num_banks, int32_t 
         if (!build_mel_lane_plan(t, num_banks, fft_size, max_read_bin, p16, fft_size == 1024 ? 4 : 2)) return MFX_ERR_CONFIG;
         rounds = p16.rounds, rs = p16.row_stride, Ls = p16.L, st = &p16.start, fd = &p16.fid, ww = &p16.w;
     } else {
-        if (!build_mel_wave_plan(t, num_banks, fft_size, max_read_bin, p64)) return MFX_ERR_CONFIG;
+        if (!build_mel_wave_plan(t, num_banks, fft_size, max_read_bin, p64, lanes)) return MFX_ERR_CONFIG;
         rounds = p64.rounds, rs = p64.row_stride, Ls = p64.L, st = &p64.start, fd = &p64.fid, ww = &p64.w;
     }
     if (L) std::memcpy(L, Ls, sizeof(int32_t) * 8);

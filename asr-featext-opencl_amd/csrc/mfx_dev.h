@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 namespace mfx {
 namespace {
 
@@ -127,6 +129,116 @@ __host__ __device__ inline int lm_stride(int nb)
     return x;
 }
 
+
+// Log mel energies of 4 frames waiting for the DCT: lm[g * FS + m]; FS = 4 q with q odd and FS > nb (the last word parks
+// idle lanes): the four frames' 16-byte operand reads then fall on distinct bank quads.
+__host__ __device__ inline int lm_fs4(int nb)
+{
+    int q = (nb + 4) / 4 + ((nb + 4) % 4 ? 1 : 0);
+    if ((q & 1) == 0) ++q;
+    return 4 * q;
+}
+
+// DCT-II + lifter of 4 frames on the matrix pipe, 64 output columns at a time: v_mfma_f32_4x4x1_16b_f32 computes 16
+// independent 4 x 4 outer products, D_b[i][j] += A_b[i] * B_b[j]; with i = frame, b = lane / 4, j = lane % 4 one
+// instruction adds ONE band m to out[frame i][column 4 b + j] for all 64 columns and all 4 frames:
+//     A operand of lane l: lm[frame l & 3][m]          B operand of lane l: dct[m][64 tile + l]
+//     result register i of lane l: out[frame i][64 tile + l]
+// Every product of the instruction is used when the row has 64 columns (40 here: 62 %), where the 16 x 16 x 4 form with
+// 4 frames used a quarter of its rows -- and on gfx950 f32 matrix instructions do not overlap the vector pipe
+// (SQ_VALU_MFMA_COEXEC_CYCLES = 0: they run on the same FP32 units), so their cycles are the SIMD's cycles: 8 per band
+// for four frames here against 32 per 4 bands and 16 columns before (C5: 3072 -> 1024 SIMD cycles per four frames).
+// Bands are accumulated in ascending order in two chains (even / odd m), as mfcccpu.cpp:222-232 sums them up to that
+// association.  Operands come four bands at a time (one 16-byte LDS read, one 16-byte buffer load; B laid out
+// [tile][band / 4][lane][4], bands past the table return 0), software pipelined without branches: the next four bands'
+// operands are requested before the current four instructions issue.
+__device__ __forceinline__ void dct_mfma4(const float *arow, __amdgpu_buffer_rsrc_t rsrc, int table_bytes, int lane, int tile,
+                                          int ks, float (&res)[4])
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+    float4 ava, avb;
+    u32x4 bva, bvb;
+    auto fetch = [&](u32x4 &bv, float4 &av, int j4) {
+        av = lds_read_b128((const float4 *)(arow + 4 * (j4 < ks ? j4 : 0)));
+        bv = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, j4 < ks ? ((tile * ks + j4) * 1024) : table_bytes, 0);
+    };
+    auto mac = [&](const u32x4 &bv, const float4 &av) {
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, __uint_as_float(bv[0]), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, __uint_as_float(bv[1]), d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, __uint_as_float(bv[2]), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, __uint_as_float(bv[3]), d1, 0, 0, 0);
+    };
+    fetch(bva, ava, 0);
+    for (int j4 = 0; j4 < ks; j4 += 2) {
+        fetch(bvb, avb, j4 + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mac(bva, ava);
+        fetch(bva, ava, j4 + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mac(bvb, avb);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) res[i] = d0[i] + d1[i];
+}
+
+// One frame's mel filterbank on the 64 lanes of a wave (MelWavePlan, lanes = 64) + log: per round every lane walks ONE
+// filter's bins in ascending order, one chain of multiply-adds (mfcccpu.cpp:206-217); weights from the lane's own
+// zero-padded row (16-byte reads, disjoint bank quads), magnitudes as 8-byte reads from even starts the host spread over
+// the banks.  mag must hold finite values up to the plan's last read.  The log energy of filter fid goes to lmf[fid]; idle
+// lanes park theirs in lmf[park].
+__device__ __forceinline__ void mel64_walk_log(const float *mag, float *lmf, int park, const float *s_mw, const int *s_mst,
+                                               const int *s_mfid, const int *Lr, int rounds, int RS, int lane)
+{
+    const float *wrow = s_mw + lane * RS;
+    for (int r = 0; r < rounds; ++r) {
+        const int st = s_mst[r * 64 + lane], fid = s_mfid[r * 64 + lane];
+        const int L = Lr[r];
+        const float *mg = mag + st;
+        float acc = 0.f;
+        for (int s2 = 0; s2 < L; s2 += 8) {
+            const float4 w0 = lds_read_b128((const float4 *)(wrow + s2));
+            const float4 w1 = lds_read_b128((const float4 *)(wrow + s2 + 4));
+            float2 mm[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mm[q] = lds_read_b64((const float2 *)(mg + s2 + 2 * q));
+            acc += w0.x * mm[0].x;
+            acc += w0.y * mm[0].y;
+            acc += w0.z * mm[1].x;
+            acc += w0.w * mm[1].y;
+            acc += w1.x * mm[2].x;
+            acc += w1.y * mm[2].y;
+            acc += w1.z * mm[3].x;
+            acc += w1.w * mm[3].y;
+        }
+        wrow += L;
+        lmf[fid >= 0 ? fid : park] = MFX_LOG(fmaxf(acc, 1e-30f));
+    }
+}
+
+// DCT of the (up to) 4 frames whose log energies wait in lm[4][FS] (lm_fs4), rows out_row0 .. out_row0 + count - 1 of
+// feat: 64 columns per pass on the matrix pipe (dct_mfma4), or -- without a DCT -- the log energies themselves.
+__device__ __forceinline__ void dct4_store(const float *lm, int FS, __amdgpu_buffer_rsrc_t rsrc, int table_bytes, int ks,
+                                           int tiles64, bool has_dct, int lane, int cols, float *feat, int64_t feat_pitch,
+                                           int64_t out_row0, int count)
+{
+    if (has_dct) {
+        const float *arow = lm + (lane & 3) * FS;
+        for (int tile = 0; tile < tiles64; ++tile) {
+            float res[4];
+            dct_mfma4(arow, rsrc, table_bytes, lane, tile, ks, res);
+            const int col = 64 * tile + lane;
+            if (col < cols) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < count) (feat + (out_row0 + i) * feat_pitch)[col] = res[i];
+            }
+        }
+    } else {
+        for (int g = 0; g < count; ++g)
+            for (int cc = lane; cc < cols; cc += 64) (feat + (out_row0 + g) * feat_pitch)[cc] = lm[g * FS + cc];
+    }
+}
 
 } // namespace
 } // namespace mfx

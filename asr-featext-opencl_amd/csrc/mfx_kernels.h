@@ -72,11 +72,6 @@ struct FrontParams {
     const float *mel_w;       // [2][W2]
     const int32_t *mel_beg;   // [nb+2]
     const float *dct;         // [nb][dct_len] or nullptr when ceps_len == 0
-    // wave-per-frame mel stage (mel_log_dct): filter pieces dealt to the 64 lanes (MelItemPlan)
-    const int32_t *mel_items;     // [mel_K][64][4]
-    const int32_t *mel_pieces;    // [nb]
-    const float *mel_item_w;      // [mel_wlen] per-piece weights (multiples of 8 floats)
-    int32_t mel_K, mel_wlen;
     // 512 fast path: mel filters dealt to the 16 lanes of a frame in `mel_rounds` rounds, round r
     // padded to mel_L[r] bins (multiple of 4); lane j's weights for all rounds are one row of mel_lane_w
     const float *mel_lane_w;      // [16][mel_row_stride]
@@ -87,7 +82,7 @@ struct FrontParams {
                                   //    4 frames (cols <= 16, num_banks <= 40; matrix from `dct`, held in registers)
     int32_t mel_rounds, mel_row_stride, dct_stride, nb_pad;
     int32_t mel_L[8];
-    // wave-per-frame lane plan (k_front_reg fused): filters dealt to the 64 lanes of the frame's wave in rounds
+    // wave-per-frame lane plan (k_front_reg / k_front_wave fused): filters dealt to the 64 lanes of the frame's wave in rounds
     const float *mel64_w;         // [64][mel64_row_stride]
     const int32_t *mel64_start;   // [mel64_rounds][64]
     const int32_t *mel64_fid;     // [mel64_rounds][64]
@@ -133,11 +128,15 @@ struct MelcepParams {
     const int32_t *mel_beg;
     const float *dct;
     int32_t num_banks, dct_len, cols;
-    const int32_t *mel_items;     // [mel_K][64][4] filter pieces dealt to the lanes (MelItemPlan)
-    const int32_t *mel_pieces;    // [nb]
-    const float *mel_item_w;      // [mel_wlen] per-piece weights
-    int32_t mel_K, mel_wlen;
-    int32_t mel_items_stride, mel_pieces_stride, mel_item_w_stride; // per table of a sweep, in elements
+    // 64-lane mel plan (MelWavePlan), one per table of a sweep, all padded to the same row stride
+    const float *mel64_w;         // [n_tables][64][mel64_row_stride]
+    const int32_t *mel64_start;   // [n_tables][mel64_rounds][64]
+    const int32_t *mel64_fid;     // [n_tables][mel64_rounds][64]
+    const int32_t *mel64_L;       // [n_tables][8] bins per lane and round (device memory)
+    int32_t mel64_rounds, mel64_row_stride;
+    int32_t mag_floats;           // LDS floats of a wave's magnitude buffer: >= spec_pitch and > the plans' last read, x4
+    const float *dct_b4;          // DCT operands of the 4x4x1 form (build_dct_mfma_operands4) or nullptr
+    int32_t dct_ksteps;
     // VTLN sweep: n_tables (>= 1) warped filterbanks over the same spectrum in one launch; table a is
     // mel_w + a * mel_w_stride / mel_beg + a * mel_beg_stride and writes feat + a * feat_table_stride
     int32_t n_tables;

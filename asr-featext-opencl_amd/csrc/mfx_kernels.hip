@@ -10,129 +10,12 @@
 
 #include "mfx_dev.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace mfx {
 
 namespace {
-
-// ------------------------------------------------------------------------------------------------
-// mel filterbank + log + DCT for ONE frame whose magnitudes sit in LDS, shared by G lanes.
-//   mag     : LDS, bins 0..W2/2 of this frame
-//   melbuf  : LDS scratch, >= num_banks floats, private to this frame's lane group
-//   g       : lane index inside the group [0, G)
-// Filter m = sum over bins [beg[m], beg[m+2]) of w[m & 1][bin] * mag[bin] in ascending bin order
-// (mfcccpu.cpp:192-220, `while` semantics for coincident edges); out[c] = sum_m mel[m]*dct[m][c] in
-// ascending m (mfcccpu.cpp:222-232).  Tables are read from LDS copies (s_*).
-// ------------------------------------------------------------------------------------------------
-// LDS floats of the scratch behind `melbuf`: the log mel energies + the partial sums of the chunked DCT
-__host__ __device__ inline int mel_scratch_floats(int nb, int cols) { return ((nb + 3) & ~3) + 8 * ((cols + 3) & ~3) + 4 * nb; }
-// block-shared LDS words of the mel work plan: items [K][64][4] + pieces [nb]
-__host__ __device__ inline int mel_plan_words(int nb, int K) { return K * 256 + ((nb + 3) & ~3); }
-
-// One filter piece: `trips` x 8 bins from the 4-aligned bin a0, weights in the piece's own padded array (exact
-// zeros outside the filter's range), summed in ascending bin order; everything comes as 16-byte LDS reads.
-// The magnitude buffer must hold FINITE values up to 10 words past the last bin (0 * x).
-__device__ __forceinline__ float mel_piece_sum(const float *w, const float *mag_a0, int trips)
-{
-    float acc = 0.f;
-    for (int t = 0; t < trips; ++t) {
-        const float4 w0 = *(const float4 *)(w + 8 * t), w1 = *(const float4 *)(w + 8 * t + 4);
-        const float4 m0 = *(const float4 *)(mag_a0 + 8 * t), m1 = *(const float4 *)(mag_a0 + 8 * t + 4);
-        acc += w0.x * m0.x;
-        acc += w0.y * m0.y;
-        acc += w0.z * m0.z;
-        acc += w0.w * m0.w;
-        acc += w1.x * m1.x;
-        acc += w1.y * m1.y;
-        acc += w1.z * m1.z;
-        acc += w1.w * m1.w;
-    }
-    return acc;
-}
-
-template <int G>
-__device__ __forceinline__ void mel_log_dct(const float *mag, float *melbuf, int g, const float *s_mw,
-                                            const int4 *s_items, const int *s_pieces, int K,
-                                            const float *s_dct, int nb, int dct_len, int cols, float *out_row)
-{
-    static_assert(G == 64, "one wave per frame");
-    // Mel filters are narrow at the bottom and wide at the top of the band.  Their bin ranges are cut into
-    // <= 4 pieces each and the pieces dealt to the lanes by the host (MelItemPlan) so that every lane walks
-    // about the same number of bins; a piece is summed in ascending bin order, a filter's pieces are added in
-    // ascending order (mfcccpu.cpp:206-215 sums the whole range in one chain: same terms, the association
-    // differs at the piece boundaries only).
-    float *mpart = melbuf + ((nb + 3) & ~3) + 8 * ((cols + 3) & ~3); // [nb][4]
-    for (int k = 0; k < K; ++k) {
-        const int4 it = s_items[k * 64 + g];
-        if (it.x >= 0) mpart[it.x] = mel_piece_sum(s_mw + it.w, mag + it.y, it.z);
-    }
-    wave_sync();
-    for (int m = g; m < nb; m += G) {
-        float acc = mpart[4 * m];
-        const int n = s_pieces[m];
-        for (int s2 = 1; s2 < n; ++s2) acc += mpart[4 * m + s2];
-        melbuf[m] = logf(fmaxf(acc, 1e-30f));
-    }
-    wave_sync();
-    if (s_dct) {
-        // DCT: out[c] = sum_m mel[m] * dct[m][c].  A work item is 4 consecutive columns over one chunk of the m
-        // range (one mel read + one 16-byte row read feed 4 multiply-adds); the chunk count n_ch is chosen so
-        // that the items fill the 64 lanes.  A chunk is summed in ascending m, the chunks are added in
-        // ascending order by the column's lane (mfcccpu.cpp:222-232 sums m = 0..nb-1 in one chain: same
-        // terms, association differs by the chunk boundaries only).  s_dct rows are padded to dl4 floats.
-        const int dl4 = (dct_len + 3) & ~3, quads = (cols + 3) >> 2, cols4 = quads * 4;
-        int n_ch = 1, best = nb; // cost ~ rounds * terms per item
-        for (int c2 = 2; c2 <= 8; c2 <<= 1) {
-            const int cost = ((quads * c2 + G - 1) / G) * ((nb + c2 - 1) / c2);
-            if (cost < best) {
-                best = cost;
-                n_ch = c2;
-            }
-        }
-        const int ch_len = (nb + n_ch - 1) / n_ch;
-        float *part = melbuf + ((nb + 3) & ~3); // [n_ch][cols4]
-        for (int it = g; it < quads * n_ch; it += G) {
-            const int ch = it / quads, q = it - ch * quads;
-            const int m0 = ch * ch_len, m1 = min(nb, m0 + ch_len);
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            int m = m0;
-            for (; m + 4 <= m1; m += 4) { // reads batched 4 deep
-                float ev[4];
-                float4 dv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    ev[u] = melbuf[m + u];
-                    dv[u] = *(const float4 *)(s_dct + (m + u) * dl4 + 4 * q);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    acc.x += ev[u] * dv[u].x;
-                    acc.y += ev[u] * dv[u].y;
-                    acc.z += ev[u] * dv[u].z;
-                    acc.w += ev[u] * dv[u].w;
-                }
-            }
-            for (; m < m1; ++m) {
-                const float e = melbuf[m];
-                const float4 d = *(const float4 *)(s_dct + m * dl4 + 4 * q);
-                acc.x += e * d.x;
-                acc.y += e * d.y;
-                acc.z += e * d.z;
-                acc.w += e * d.w;
-            }
-            *(float4 *)(part + ch * cols4 + 4 * q) = acc;
-        }
-        wave_sync();
-        for (int c = g; c < cols; c += G) {
-            float acc = part[c];
-            for (int ch = 1; ch < n_ch; ++ch) acc += part[ch * cols4 + c];
-            out_row[c] = acc;
-        }
-    } else {
-        for (int c = g; c < cols; c += G) out_row[c] = melbuf[c];
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // 512-point front end.  One wave owns 4 frames per iteration, 16 lanes per frame; a 512-thread
@@ -1428,29 +1311,30 @@ __global__ void __launch_bounds__(256) k_front_wave(FrontParams p)
     };
     const int W2 = p.fft_size, M = W2 >> 1;
     const int nb = p.num_banks, dl = p.dct_len;
-    // shared tables (FUSED only), then per wave: two complex buffers of M points + mel scratch
-    float *s_mw = smem;                                       // per-piece mel weights
-    int4 *s_items = (int4 *)(s_mw + (FUSED ? p.mel_wlen : 0)); // mel work plan: items [K][64], then pieces [nb]
-    int *s_pieces = (int *)s_items + p.mel_K * 256;
-    float *s_dct = (float *)((int *)s_items + (FUSED ? mel_plan_words(nb, p.mel_K) : 0));
-    const int dl4 = (dl + 3) & ~3;               // DCT rows padded to whole 16-byte words in LDS
-    const int dct_floats = (FUSED && p.dct) ? nb * dl4 : 0;
-    const int dct_pad = dct_floats;
-    const int nb_pad = FUSED ? mel_scratch_floats(nb, p.cols) : 0;
-    float *s_wave = s_dct + dct_pad + wave * (4 * M + nb_pad);
+    // shared tables (FUSED only: the 64-lane mel plan, MelWavePlan), then per wave: two complex buffers of M points and the
+    // log mel energies of 4 frames waiting for the DCT (lm_fs4)
+    const int RS = FUSED ? p.mel64_row_stride : 0, rounds = FUSED ? p.mel64_rounds : 0;
+    float *s_mw = smem;                                       // [64][RS]
+    int *s_mst = (int *)(s_mw + 64 * RS);                     // [rounds][64]
+    int *s_mfid = s_mst + 64 * rounds;                        // [rounds][64]
+    const int FS = FUSED ? lm_fs4(nb) : 0;
+    float *s_wave = (float *)(s_mfid + 64 * rounds) + wave * (4 * M + 4 * FS);
     float2 *bufA = (float2 *)s_wave;
     float2 *bufB = bufA + M;
-    float *s_mel = s_wave + 4 * M;
+    float *lm = s_wave + 4 * M;                               // [4][FS]
+    (void)dl;
     if (FUSED) {
-        for (int i = tid; i < p.mel_wlen; i += 256) s_mw[i] = p.mel_item_w[i];
-        for (int i = tid; i < p.mel_K * 256; i += 256) ((int *)s_items)[i] = p.mel_items[i];
-        for (int i = tid; i < nb; i += 256) s_pieces[i] = p.mel_pieces[i];
-        for (int i = tid; i < dct_floats; i += 256) {
-            const int m = i / dl4, c = i - m * dl4;
-            s_dct[i] = c < dl ? p.dct[m * dl + c] : 0.f;
+        for (int i = tid; i < 64 * RS; i += 256) s_mw[i] = p.mel64_w[i];
+        for (int i = tid; i < 64 * rounds; i += 256) {
+            s_mst[i] = p.mel64_start[i];
+            s_mfid[i] = p.mel64_fid[i];
         }
+        for (int i = lane; i < 4 * M + 4 * FS; i += G) s_wave[i] = 0.f; // words read before they are written: finite
     }
     __syncthreads();
+    const int dct_ks = p.dct_ksteps, dct_tiles64 = (dl + 63) >> 6;
+    const int dct_bytes = (FUSED && p.dct_b4) ? dct_tiles64 * dct_ks * 1024 : 0;
+    const __amdgpu_buffer_rsrc_t dct_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.dct_b4, 0, dct_bytes, 0x00020000);
 
     const float2 *tw = (const float2 *)p.twid_half;   // W_M^k, k < M
     const float2 *cs = (const float2 *)p.twid_split;  // -i W_{W2}^k, k <= M
@@ -1459,7 +1343,9 @@ __global__ void __launch_bounds__(256) k_front_wave(FrontParams p)
 
     for (int c = blockIdx.x * NG + wave; c < p.n_chunks; c += gridDim.x * NG) {
         const Chunk ch = p.chunks[c];
-        for (int f = 0; f < ch.n_frames && (ch.out_row + f) < p.row_limit; ++f) {
+        const int64_t rows_left = p.row_limit - ch.out_row;
+        const int nf = (int)(rows_left < ch.n_frames ? (rows_left < 0 ? 0 : rows_left) : ch.n_frames);
+        for (int f = 0; f < nf; ++f) {
             const int64_t s0 = ch.pcm_off + (int64_t)f * p.shift;
             // ---- framing + window: z[n] = (w[2n] x[2n], w[2n+1] x[2n+1]), zero beyond the window
             for (int n = lane; n < M; n += G) {
@@ -1541,9 +1427,16 @@ __global__ void __launch_bounds__(256) k_front_wave(FrontParams p)
             }
             group_sync();
             if (FUSED) {
-                mel_log_dct<G>(mag, s_mel, lane, s_mw, s_items, s_pieces, p.mel_K, p.dct ? s_dct : nullptr, nb, dl, p.cols,
-                                p.feat + (ch.out_row + f) * (int64_t)p.feat_pitch);
+                // mel walk on the wave's 64 lanes + log (the magnitudes sit in the 2 M floats of the other buffer: the plan
+                // reads at most up to word W2 - 1, stale but finite beyond bin M); DCT once per 4 frames and at the chunk's end
+                mel64_walk_log(mag, lm + (f & 3) * FS, FS - 1, s_mw, s_mst, s_mfid, p.mel64_L, rounds, RS, lane);
                 group_sync();
+                if ((f & 3) == 3 || f == nf - 1) {
+                    const int g0 = f & ~3;
+                    dct4_store(lm, FS, dct_rsrc, dct_bytes, dct_ks, dct_tiles64, p.dct_b4 != nullptr, lane, p.cols, p.feat,
+                               (int64_t)p.feat_pitch, ch.out_row + g0, f - g0 + 1);
+                    group_sync();
+                }
             }
         }
     }
@@ -2050,47 +1943,58 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
 }
 
 // ------------------------------------------------------------------------------------------------
-// melcep: stored magnitudes -> mel -> log -> DCT.  One wave per frame, 4 waves per block.
+// melcep: stored magnitudes -> mel -> log -> DCT (streaming apply(), VTLN sweeps, the 4096-point batch path).  A wave
+// takes 4 consecutive rows at a time: each row's magnitudes go to the wave's LDS buffer, its filters are walked on the
+// wave's 64 lanes (MelWavePlan: whole filters in ascending bin order, mfcccpu.cpp:206-217), the log energies wait in
+// lm[4][FS], and the DCT of the four rows runs on the matrix pipe (dct_mfma4) -- the same mel stage as the fused batch
+// kernels (round 3: the round-1 piece plan and its vector-pipe DCT are gone).  blockIdx.y = filterbank of a VTLN sweep.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_melcep(MelcepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int W2 = p.fft_size, nbins = (W2 >> 1) + 1;
-    const int bins_pad = (nbins + 12 + 3) & ~3;  // + slack: the mel pieces read up to 10 words past the last bin
-    const int nb = p.num_banks, dl = p.dct_len;
-    float *s_mw = smem;                                      // per-piece mel weights
-    int4 *s_items = (int4 *)(s_mw + p.mel_wlen);             // mel work plan: items [K][64], then pieces [nb]
-    int *s_pieces = (int *)s_items + p.mel_K * 256;
-    float *s_dct = (float *)((int *)s_items + mel_plan_words(nb, p.mel_K));
-    const int dl4 = (dl + 3) & ~3;               // DCT rows padded to whole 16-byte words in LDS
-    const int dct_floats = p.dct ? nb * dl4 : 0;
-    const int dct_pad = dct_floats;
-    const int nb_pad = mel_scratch_floats(nb, p.cols);
-    float *s_mag = s_dct + dct_pad + wave * (bins_pad + nb_pad);
-    float *s_mel = s_mag + bins_pad;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
+    const int nb = p.num_banks, RS = p.mel64_row_stride, rounds = p.mel64_rounds;
+    const int FS = lm_fs4(nb), MF = p.mag_floats;
+    float *s_mw = smem;                              // [64][RS]
+    int *s_mst = (int *)(s_mw + 64 * RS);            // [rounds][64]
+    int *s_mfid = s_mst + 64 * rounds;               // [rounds][64]
+    int *s_L = s_mfid + 64 * rounds;                 // [8]
+    float *s_wave = (float *)(s_L + 8) + wave * (MF + 4 * FS);
+    float *mag = s_wave, *lm = s_wave + MF;
 
-    // blockIdx.y = filterbank of a VTLN sweep (one table per alpha over the same spectrum)
-    const float *mel_item_w = p.mel_item_w + (int64_t)blockIdx.y * p.mel_item_w_stride;
-    const int32_t *mel_items = p.mel_items + (int64_t)blockIdx.y * p.mel_items_stride;
-    const int32_t *mel_pieces = p.mel_pieces + (int64_t)blockIdx.y * p.mel_pieces_stride;
-    float *feat = p.feat + (int64_t)blockIdx.y * p.feat_table_stride;
-    for (int i = tid; i < p.mel_wlen; i += 256) s_mw[i] = mel_item_w[i];
-    for (int i = tid; i < p.mel_K * 256; i += 256) ((int *)s_items)[i] = mel_items[i];
-    for (int i = tid; i < nb; i += 256) s_pieces[i] = mel_pieces[i];
-    for (int i = tid; i < dct_floats; i += 256) {
-        const int m = i / dl4, c = i - m * dl4;
-        s_dct[i] = c < dl ? p.dct[m * dl + c] : 0.f;
+    const int table = blockIdx.y;
+    const float *gw = p.mel64_w + (int64_t)table * 64 * RS;
+    const int32_t *gst = p.mel64_start + (int64_t)table * 64 * rounds, *gfid = p.mel64_fid + (int64_t)table * 64 * rounds;
+    float *feat = p.feat + (int64_t)table * p.feat_table_stride;
+    for (int i = tid; i < 64 * RS; i += blockDim.x) s_mw[i] = gw[i];
+    for (int i = tid; i < 64 * rounds; i += blockDim.x) {
+        s_mst[i] = gst[i];
+        s_mfid[i] = gfid[i];
     }
-    for (int i = lane; i < bins_pad; i += 64) s_mag[i] = 0.f; // the slack words stay zero (finite) for good
+    if (tid < 8) s_L[tid] = p.mel64_L[table * 8 + tid];
+    for (int i = lane; i < MF + 4 * FS; i += 64) s_wave[i] = 0.f; // words past the last bin stay zero (finite) for good
     __syncthreads();
 
-    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < p.n_rows; r += (int64_t)gridDim.x * 4) {
-        const float *src = p.spec + r * p.spec_pitch;
-        for (int k = lane; k < nbins; k += 64) s_mag[k] = src[k];
-        wave_sync();
-        mel_log_dct<64>(s_mag, s_mel, lane, s_mw, s_items, s_pieces, p.mel_K, p.dct ? s_dct : nullptr, nb, dl, p.cols,
-                        feat + r * p.feat_pitch);
+    const int dct_ks = p.dct_ksteps, dct_tiles64 = (p.dct_len + 63) >> 6;
+    const int dct_bytes = p.dct_b4 ? dct_tiles64 * dct_ks * 1024 : 0;
+    const __amdgpu_buffer_rsrc_t dct_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.dct_b4, 0, dct_bytes, 0x00020000);
+    const int q4 = p.spec_pitch >> 2; // rows are whole 16-byte words (spec_pitch is a multiple of 4, rows 16-byte aligned)
+    const int nbins = (p.fft_size >> 1) + 1;
+    for (int64_t grp = (int64_t)blockIdx.x * n_waves + wave; grp * 4 < p.n_rows; grp += (int64_t)gridDim.x * n_waves) {
+        const int64_t row0 = grp * 4;
+        const int count = (int)(p.n_rows - row0 < 4 ? p.n_rows - row0 : 4);
+        for (int f = 0; f < count; ++f) {
+            const float4 *src = (const float4 *)(p.spec + (row0 + f) * p.spec_pitch);
+            for (int k = lane; k < q4; k += 64) ((float4 *)mag)[k] = src[k];
+            // the row's padding words (bins > W2/2) are never written in memory: they meet zero weights in the walk and
+            // must be finite (0 x NaN is NaN)
+            if (nbins + lane < 4 * q4) mag[nbins + lane] = 0.f;
+            wave_sync();
+            mel64_walk_log(mag, lm + f * FS, FS - 1, s_mw, s_mst, s_mfid, s_L, rounds, RS, lane);
+            wave_sync();
+        }
+        dct4_store(lm, FS, dct_rsrc, dct_bytes, dct_ks, dct_tiles64, p.dct_b4 != nullptr, lane, p.cols, feat, (int64_t)p.feat_pitch,
+                   row0, count);
         wave_sync();
     }
 }
@@ -2590,11 +2494,8 @@ size_t front_wave_lds_bytes(const FrontParams &p, bool fused)
     }
     const int M = p.fft_size >> 1;
     size_t f = 0;
-    if (fused) {
-        f += (size_t)p.mel_wlen + mel_plan_words(p.num_banks, p.mel_K);
-        f += p.dct ? (size_t)p.num_banks * ((p.dct_len + 3) & ~3) : 0;
-    }
-    f += 4 * ((size_t)4 * M + (fused ? mel_scratch_floats(p.num_banks, p.cols) : 0));
+    if (fused) f += (size_t)64 * p.mel64_row_stride + (size_t)128 * p.mel64_rounds; // lane weight rows, starts + filter ids
+    f += 4 * ((size_t)4 * M + (fused ? 4 * (size_t)lm_fs4(p.num_banks) : 0));
     return f * sizeof(float);
 }
 
@@ -2625,24 +2526,32 @@ hipError_t launch_front_generic(const FrontParams &p, bool fused, hipStream_t st
     return hipGetLastError();
 }
 
+size_t melcep_lds_bytes(const MelcepParams &p, int n_waves)
+{
+    const size_t f = (size_t)64 * p.mel64_row_stride + (size_t)128 * p.mel64_rounds + 8 +
+                     (size_t)n_waves * ((size_t)p.mag_floats + 4 * (size_t)lm_fs4(p.num_banks));
+    return f * sizeof(float);
+}
+
 hipError_t launch_melcep(const MelcepParams &p, hipStream_t stream)
 {
     if (p.n_rows <= 0) return hipSuccess;
-    const int nbins = (p.fft_size >> 1) + 1, bins_pad = (nbins + 12 + 3) & ~3;
-    const int nb = p.num_banks;
-    size_t f = (size_t)p.mel_wlen + mel_plan_words(nb, p.mel_K) + (p.dct ? nb * ((p.dct_len + 3) & ~3) : 0) +
-               4 * (bins_pad + mel_scratch_floats(nb, p.cols));
-    const size_t lds = f * sizeof(float);
+    if (p.mag_floats < p.spec_pitch || (p.spec_pitch & 3) || (p.mag_floats & 3)) return hipErrorInvalidValue;
+    int nw = 4; // waves per block: as many of 4 as the LDS holds
+    while (nw > 1 && melcep_lds_bytes(p, nw) > 160 * 1024) nw >>= 1;
+    const size_t lds = melcep_lds_bytes(p, nw);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)k_melcep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    int64_t blocks = (p.n_rows + 3) / 4;
-    const int cap = num_cus() * 8;
+    int64_t blocks = ((p.n_rows + 3) / 4 + nw - 1) / nw;
+    const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
+    const int cap = num_cus() * (per_cu < 1 ? 1 : per_cu);
     if (blocks > cap) blocks = cap;
     const int tables = p.n_tables > 1 ? p.n_tables : 1;
     if (tables > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_melcep, dim3((unsigned)blocks, (unsigned)tables), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(k_melcep, dim3((unsigned)blocks, (unsigned)tables), dim3(64 * nw), lds, stream, p);
     return hipGetLastError();
 }
 

@@ -269,62 +269,4 @@ void build_dct_transposed(const std::vector<float> &dct, int num_banks, int dct_
         for (int c = 0; c < dct_len; ++c) out[(size_t)c * stride + m] = dct[(size_t)m * dct_len + c];
 }
 
-void build_mel_item_plan(const MelTable &t, int num_banks, int fft_size, MelItemPlan &out)
-{
-    const std::vector<int32_t> &beg = t.beg;
-    struct Item {
-        int slot, b0, b1;
-    };
-    std::vector<Item> items;
-    out.pieces.assign((size_t)num_banks, 1);
-    for (int m = 0; m < num_banks; ++m) {
-        const int b0 = beg[m], b1 = beg[m + 2], len = b1 - b0;
-        int n = (len + 15) / 16; // pieces of <= 16 bins, at most 4 (longer filters get longer pieces)
-        if (n < 1) n = 1;
-        if (n > 4) n = 4;
-        out.pieces[m] = n;
-        const int step = ((len + n - 1) / n + 7) & ~7; // multiples of 8: whole 8-bin read batches
-        for (int s = 0; s < n; ++s) {
-            const int lo = b0 + s * step, hi = std::min(b1, lo + step);
-            items.push_back({4 * m + s, std::min(lo, b1), hi}); // an empty piece contributes an exact 0
-        }
-    }
-    std::vector<int> order(items.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        return items[a].b1 - items[a].b0 > items[b].b1 - items[b].b0;
-    });
-    std::vector<std::vector<int>> lane_items(64);
-    std::vector<int> load(64, 0);
-    for (int id : order) {
-        int best = 0;
-        for (int l = 1; l < 64; ++l)
-            if (load[l] < load[best]) best = l;
-        lane_items[best].push_back(id);
-        load[best] += items[id].b1 - items[id].b0 + 4; // + a constant per item (loop set-up, the store)
-    }
-    size_t K = 1;
-    for (auto &v : lane_items) K = std::max(K, v.size());
-    out.K = (int)K;
-    out.items.assign(K * 64 * 4, 0);
-    out.w.clear();
-    for (size_t k = 0; k < K; ++k)
-        for (int l = 0; l < 64; ++l) {
-            int32_t *e = &out.items[(k * 64 + l) * 4];
-            if (k >= lane_items[l].size()) {
-                e[0] = -1;
-                continue;
-            }
-            const Item &it = items[lane_items[l][k]];
-            const int a0 = it.b0 & ~3, trips = (it.b1 - a0 + 7) / 8;
-            const float *row = t.weights.data() + (size_t)(((it.slot >> 2) & 1) ? fft_size : 0);
-            e[0] = it.slot;
-            e[1] = a0;
-            e[2] = trips;
-            e[3] = (int32_t)out.w.size();
-            for (int j = a0; j < a0 + 8 * trips; ++j) out.w.push_back((j >= it.b0 && j < it.b1) ? row[j] : 0.0f);
-        }
-    if (out.w.empty()) out.w.assign(8, 0.0f);
-}
-
 } // namespace mfx

@@ -92,21 +92,4 @@ void build_dct_mfma_operands4(const std::vector<float> &dct, int num_banks, int 
 void build_dct_transposed(const std::vector<float> &dct, int num_banks, int dct_len, int &stride, int &nb_pad,
                           std::vector<float> &out);
 
-// Work plan of the wave-per-frame mel stage (mel_log_dct): every filter's bin range is cut into <= 4
-// consecutive pieces of <= ~16 bins, the pieces are dealt to the 64 lanes so that all lanes walk about the
-// same number of bins (longest piece first, to the least loaded lane).  Each piece carries its own weights,
-// laid out for 16-byte reads: the piece is widened to start at a multiple of 4 bins and to a whole number of
-// 8-bin trips, with exact zeros outside the filter's own range (adding them changes no bit of the sum).
-//   items  : [K][64][4] = {slot, first bin (multiple of 4), trips of 8 bins, offset into w}; slot = 4 * filter +
-//            piece, or -1 for an idle entry
-//   w      : the pieces' weights, 8 * trips floats each
-//   pieces : [num_banks] number of pieces of each filter (its partial sums are added in ascending order)
-struct MelItemPlan {
-    int K = 0;
-    std::vector<int32_t> items;
-    std::vector<float> w;
-    std::vector<int32_t> pieces;
-};
-void build_mel_item_plan(const MelTable &t, int num_banks, int fft_size, MelItemPlan &out);
-
 } // namespace mfx

@@ -56,7 +56,7 @@ EXPORTED_SYMBOLS = (
     "mfx_create", "mfx_destroy", "mfx_last_error", "mfx_status_string", "mfx_abi_version",
     "mfx_set_window", "mfx_set_input", "mfx_flush", "mfx_set_alpha", "mfx_apply",
     "mfx_get_output_data_width", "mfx_get_output_data", "mfx_get_input_buffer_size",
-    "mfx_apply_alphas", "mfx_get_output_data_alpha", "mfx_host_mel_item_plan", "mfx_host_mel_lane_plan",
+    "mfx_apply_alphas", "mfx_get_output_data_alpha", "mfx_host_mel_lane_plan",
     "mfx_host_dct_mfma_operands",
     "mfx_estimated_window_count", "mfx_max_frames_out", "mfx_fft_size",
     "mfx_batch_frames", "mfx_batch_plan", "mfx_batch_run_device", "mfx_batch_run_host", "mfx_batch_overlap",
@@ -126,8 +126,6 @@ def load_library():
     L.mfx_host_mel_table.argtypes = [i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, fp, C.POINTER(i32)]
     L.mfx_host_dct_matrix.argtypes = [i32, i32, i32, C.c_float, fp]
     L.mfx_host_frame_count.argtypes, L.mfx_host_frame_count.restype = [i64, i32, i32], i64
-    L.mfx_host_mel_item_plan.argtypes = [i32, i32, fp, C.POINTER(i32), C.POINTER(i32), i64, C.POINTER(i32), fp, i64,
-                                         C.POINTER(i64)]
     _lib = L
     return L
 
@@ -145,7 +143,7 @@ def host_mel_table(num_banks, fft_size, sample_rate, low_freq, high_freq, alpha=
 
 
 def host_mel_lane_plan(lanes, weights, beg, max_read_bin):
-    """Lane plan of the fused kernels' mel walk (lanes = 16 or 64): dict(rounds, L, row_stride, start, fid, w)."""
+    """Lane plan of the fused kernels' mel walk (lanes = 16, 32 or 64): dict(rounds, L, row_stride, start, fid, w)."""
     L = load_library()
     weights = np.ascontiguousarray(weights, dtype=np.float32)
     beg = np.ascontiguousarray(beg, dtype=np.int32)
@@ -184,29 +182,6 @@ def host_dct_mfma_operands(matrix):
     out = np.zeros(n, np.float32)
     fn(nb, dl, m.ctypes.data_as(fpt), out.ctypes.data_as(fpt), out.size, C.byref(tl), C.byref(ks))
     return out.reshape(tl.value, ks.value, 64)
-
-
-def host_mel_item_plan(weights, beg):
-    """Work plan of the wave-per-frame mel stage for a mel table (host_mel_table): items [K][64][4], pieces [nb] and
-    the pieces' zero-padded weights."""
-    L = load_library()
-    weights = np.ascontiguousarray(weights, dtype=np.float32)
-    beg = np.ascontiguousarray(beg, dtype=np.int32)
-    nb, fft = beg.size - 2, weights.shape[1]
-    ip, fpt = C.POINTER(C.c_int32), C.POINTER(C.c_float)
-    wlen = C.c_int64(0)
-    K = L.mfx_host_mel_item_plan(nb, fft, weights.ctypes.data_as(fpt), beg.ctypes.data_as(ip), None, 0, None, None, 0,
-                                 C.byref(wlen))
-    if K < 0:
-        raise MfxError(K, "mfx_host_mel_item_plan failed")
-    items = np.zeros((K, 64, 4), dtype=np.int32)
-    pieces = np.zeros(nb, dtype=np.int32)
-    w = np.zeros(wlen.value, dtype=np.float32)
-    rc = L.mfx_host_mel_item_plan(nb, fft, weights.ctypes.data_as(fpt), beg.ctypes.data_as(ip), items.ctypes.data_as(ip),
-                                  items.size, pieces.ctypes.data_as(ip), w.ctypes.data_as(fpt), w.size, C.byref(wlen))
-    if rc != K:
-        raise MfxError(rc, "mfx_host_mel_item_plan failed")
-    return items, pieces, w
 
 
 def host_dct_matrix(num_banks, ceps_len, want_c0, lift_coef):

@@ -196,14 +196,6 @@ int mfx_host_mel_table(int32_t num_banks, int32_t fft_size, float sample_rate, f
                        float alpha, float *weights, int32_t *beg);
 /* DCT-II + lifter matrix (mfcccpu.cpp:118-136): [num_banks][ceps_len + (want_c0 ? 1 : 0)] */
 int mfx_host_dct_matrix(int32_t num_banks, int32_t ceps_len, int32_t want_c0, float lift_coef, float *matrix);
-/* Work plan of the wave-per-frame mel stage for a mel table (weights [2][fft_size], beg [num_banks + 2]): the bin
- * range of every filter cut into <= 4 pieces, dealt to 64 lanes, each piece with its own zero-padded weights.
- * items: [K][64][4] int32 = {4 * filter + piece or -1, first bin (multiple of 4), trips of 8 bins, offset into w};
- * pieces: [num_banks] piece count per filter; w: the pieces' weights.  Returns K (items per lane) or a negative
- * status and stores the number of weights in *w_len; with items == NULL only K and *w_len are computed. */
-int mfx_host_mel_item_plan(int32_t num_banks, int32_t fft_size, const float *weights, const int32_t *beg,
-                           int32_t *items, int64_t items_cap, int32_t *pieces, float *w, int64_t w_cap,
-                           int64_t *w_len);
 /* Lane plan of the mel walk of the fused kernels (lanes = 16: 512-point kernel, and with fft_size = 1024 the short-window
  * 1024-point kernel, whose starts are multiples of 4 bins; lanes = 64: long-transform kernel): filters dealt to the lanes
  * in rounds, longest first; returns the number of rounds.  Test / inspection aid. */

@@ -89,55 +89,19 @@ def test_dct_matrix_equals_oracle(pkg, orc, nb, nc, c0, lift):
         assert np.all(m[:, nc] == np.float32(np.sqrt(2.0 / nb)))  # c0 is the LAST column
 
 
-@pytest.mark.parametrize("nb,W2,sr,alpha", [(40, 512, 16000.0, 1.0), (80, 1024, 16000.0, 1.0), (128, 2048, 44100.0, 1.0),
-                                             (26, 512, 16000.0, 0.88), (3, 64, 8000.0, 1.0), (128, 4096, 96000.0, 1.12)])
-def test_mel_item_plan_covers_every_bin_once(pkg, nb, W2, sr, alpha):
-    """The work plan of the wave-per-frame mel stage (pieces of every filter's bin range dealt to 64 lanes, each
-    with its own zero-padded weights): over a filter's pieces, taken in order, every bin of the filter carries its
-    table weight exactly once and in ascending order, every other entry is an exact zero; piece counts are right;
-    reads stay within 10 words of the last bin; the lanes' loads are even."""
-    wt, beg = pkg.host_mel_table(nb, W2, sr, 64.0, sr / 2, alpha)
-    items, pieces, w = pkg.host_mel_item_plan(wt, beg)
-    K = items.shape[0]
-    seen = {}
-    loads = np.zeros(64, dtype=np.int64)
-    for k in range(K):
-        for lane in range(64):
-            slot, a0, trips, off = (int(v) for v in items[k, lane])
-            if slot < 0:
-                continue
-            m, piece = divmod(slot, 4)
-            assert 0 <= m < nb and piece < pieces[m] and a0 % 4 == 0 and off % 8 == 0 and trips >= 0
-            assert a0 + 8 * trips <= W2 // 2 + 1 + 10
-            assert (m, piece) not in seen
-            seen[(m, piece)] = (a0, w[off:off + 8 * trips])
-            loads[lane] += 8 * trips
-    assert len(seen) == int(pieces.sum())
-    for m in range(nb):
-        assert 1 <= pieces[m] <= 4
-        got = np.zeros(W2 // 2 + 16, dtype=np.float32)
-        last_bin = -1
-        for piece in range(pieces[m]):
-            a0, wp = seen[(m, piece)]
-            nz = np.nonzero(wp)[0]
-            if nz.size:
-                assert a0 + nz[0] > last_bin          # pieces ascend, no bin twice
-                last_bin = a0 + nz[-1]
-            got[a0:a0 + wp.size] += wp
-        want = np.zeros_like(got)
-        b0, b1 = int(beg[m]), int(beg[m + 2])
-        want[b0:b1] = wt[m & 1, b0:b1]
-        assert np.array_equal(got, want)
-    longest = max((wp.size for _, wp in seen.values()), default=0)
-    assert loads.max() <= loads.sum() / 64 + longest + 8
-
-
 @pytest.mark.parametrize("lanes,nb,W2,sr,alpha,max_read", [
     (16, 40, 512, 16000.0, 1.0, 479), (16, 26, 512, 16000.0, 0.88, 479), (16, 15, 512, 16000.0, 1.12, 479),
     (16, 80, 1024, 16000.0, 1.0, 527), (16, 64, 1024, 16000.0, 0.9, 527), (64, 80, 1024, 16000.0, 1.0, 1023), (64, 128, 2048, 44100.0, 1.0, 1535), (64, 23, 1024, 22050.0, 0.94, 1023),
-    (64, 200, 2048, 44100.0, 1.0, 1535)])
+    (64, 200, 2048, 44100.0, 1.0, 1535),
+    # the 64-lane plan now serves every transform size (k_melcep, k_front_wave): buffers of W2 floats
+    (64, 40, 512, 16000.0, 1.0, 511), (64, 26, 512, 16000.0, 0.88, 511), (64, 3, 64, 8000.0, 1.0, 63),
+    (64, 128, 4096, 96000.0, 1.12, 4095), (64, 15, 256, 8000.0, 1.0, 255),
+    # 32 lanes per frame, two frames per wave: k_front2048 (planes of 1040 floats)
+    (32, 128, 2048, 44100.0, 1.0, 1039), (32, 96, 2048, 48000.0, 0.93, 1039), (32, 200, 2048, 32000.0, 1.07, 1039),
+    (32, 40, 2048, 44100.0, 1.0, 1039)])
 def test_mel_lane_plan_walks_every_filter_once(pkg, lanes, nb, W2, sr, alpha, max_read):
-    """Lane plans of the fused kernels' mel walk (16 lanes per frame: k_front512; 64: k_front_reg): every filter sits in
+    """Lane plans of the kernels' mel walk (16 lanes per frame: k_front512 / k_front1024; 32: k_front2048; 64: k_front_reg,
+    k_front_wave, k_melcep): every filter sits in
     exactly one (round, lane) slot; the lane's zero-padded weight row holds the filter's table weights at its bins, in
     ascending order (one chain of multiply-adds = the reference's summation order, mfcccpu.cpp:192-220), and exact zeros
     everywhere else; starts are even, rounds are whole 8-bin trips, reads stay inside the magnitude buffer; row strides

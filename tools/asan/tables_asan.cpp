@@ -1,5 +1,5 @@
 // Sanitizer run of the host table builders (csrc/mfx_tables.cpp) under -fsanitize=address,undefined: mel table, DCT
-// matrix, twiddles, the 16-lane mel plan of the 512-point kernel and the 64-lane item plan, over a grid of
+// matrix, twiddles, the 16-lane mel plan of the 512-point kernel and the 64- and 32-lane wave plans, over a grid of
 // configurations (bank counts, transform sizes, sample rates, band edges, VTLN warps).  Built by `make -C csrc asan`.
 #include <cstdio>
 #include <vector>
@@ -27,8 +27,9 @@ int main()
                             mfx::MelLanePlan lp;
                             (void)mfx::build_mel_lane_plan(t, nb, fft, 511 - 32, lp);
                         }
-                        mfx::MelItemPlan ip;
-                        mfx::build_mel_item_plan(t, nb, fft, ip);
+                        mfx::MelWavePlan wp;
+                        (void)mfx::build_mel_wave_plan(t, nb, fft, fft - 1, wp, 64);
+                        if (fft == 2048) (void)mfx::build_mel_wave_plan(t, nb, fft, 1039, wp, 32);
                         for (int ceps : {0, 1, 12, 13, 40}) {
                             if (ceps == 0) continue;
                             std::vector<float> m, mt;
