@@ -1596,13 +1596,14 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
 
     // Which front end: the 512-point register kernel, else the fused wave-per-frame kernel when its
     // LDS fits, else spectrum through an HBM slab + melcep.
-    const bool fused512 = h->fast512 && h->fused_ok;
-    const bool fused1024 = h->fast1024 && h->fused_ok && (h->W <= 512 || h->batch_aligned); // (long windows: aligned frames only)
+    const bool allow_fused = !(h->cfg.engine & MFX_ENGINE_STREAM_KERNELS); // (else: the streaming interface's kernels)
+    const bool fused512 = allow_fused && h->fast512 && h->fused_ok;
+    const bool fused1024 = allow_fused && h->fast1024 && h->fused_ok && (h->W <= 512 || h->batch_aligned); // (long windows: aligned frames only)
     // (up to 2048 points the fused form saves the spectrum's round trip through HBM -- 8 KB per frame at 2048
     // points; at 4096 points the tables + per-wave buffers no longer leave enough waves per CU)
     // (2048 points, window <= 1152 samples: two frames per wave; mono needs aligned sample pairs)
-    const bool fused2048 = h->fast2048 && h->wplan32_ok && (h->channels == 2 || p.pair_ok);
-    const bool fusedgen = !fused512 && !fused1024 && !fused2048 && h->W2 <= 2048 && h->wplan_ok &&
+    const bool fused2048 = allow_fused && h->fast2048 && h->wplan32_ok && (h->channels == 2 || p.pair_ok);
+    const bool fusedgen = allow_fused && !fused512 && !fused1024 && !fused2048 && h->W2 <= 2048 && h->wplan_ok &&
                           front_wave_lds_bytes(p, true) <= 160 * 1024;
     // With deltas on, the front end writes its statics as compact 64-byte rows into a scratch buffer
     // and the delta kernel emits whole [static | d | dd] rows: every HBM write is then a full line
@@ -1744,6 +1745,18 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
     return MFX_OK;
 }
 } // namespace
+
+extern "C" void *mfx_alloc_pinned(size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+extern "C" void mfx_free_pinned(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
 
 extern "C" int mfx_batch_overlap(mfx_handle *h, int enable)
 {

@@ -7,6 +7,14 @@
 //   afet_hip [options] in1.wav out1.txt [in2.wav out2.txt ...]
 // Inputs: RIFF/WAVE or NIST SPHERE (the reference's sample1.wav), 16-bit PCM.  --htk writes HTK
 // parameter files instead of text (the reference's binary branch is a stub).
+//
+// Files that the reference's loop would consume as ONE block (no longer than --sample-limit; one alpha) are not pushed
+// through set_input / apply / get_output_data one by one: a worker drains the queue into batches of up to --batch-mb of
+// PCM, packs them into one pinned buffer and runs ONE mfx_batch_plan + mfx_batch_run_host per batch (a 7 s file is ~1 us
+// of kernel work against ~130 us of per-call overhead), while helper threads read the next batch's files and format /
+// write the previous batch's rows.  The extractor is created with MFX_ENGINE_STREAM_KERNELS, so the rows are the same
+// bits the per-file loop delivers, and the reference's single-block flush behaviour (B1, --bug-compat) is applied to them:
+// the outputs are byte-identical to the per-file loop's (--batch-mb 0 selects that loop; tests compare the two).
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -23,6 +31,7 @@
 #include <vector>
 
 #include "afet_param.h"
+#include "../../include/mfx.h"
 
 namespace {
 
@@ -36,6 +45,8 @@ struct Options {
     bool bug_compat = true;
     bool htk = false; // binary output in HTK parameter-file format instead of the reference's text rows
     int format_threads = 4; // threads that format the text rows of a block (per worker)
+    int batch_mb = 16;      // PCM per batch of files (0: the per-file loop only); small enough that a few thousand files pipeline
+    int io_threads = 12;    // helper threads of a worker that read files and format / write rows of a batch
     std::vector<int> devices; // --devs a,b,...: one worker (own MfccHip, own thread) per entry
 };
 
@@ -86,9 +97,17 @@ Wav read_wav(const std::string &path)
     FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) throw std::runtime_error("Can't open \"" + path + "\"");
     std::vector<unsigned char> b;
-    unsigned char buf[65536];
-    size_t n;
-    while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) b.insert(b.end(), buf, buf + n);
+    std::fseek(f, 0, SEEK_END);
+    const long fsz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    if (fsz > 0) { // one read of the whole file
+        b.resize((size_t)fsz);
+        b.resize(std::fread(b.data(), 1, (size_t)fsz, f));
+    } else { // (not seekable)
+        unsigned char buf[65536];
+        size_t n;
+        while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) b.insert(b.end(), buf, buf + n);
+    }
     std::fclose(f);
     if (b.size() >= 16 && std::memcmp(b.data(), "NIST_1A", 7) == 0) return read_sphere(b, path);
     if (b.size() < 12 || std::memcmp(b.data(), "RIFF", 4) != 0 || std::memcmp(b.data() + 8, "WAVE", 4) != 0)
@@ -164,6 +183,49 @@ inline char *put_f(char *p, char *end, double v)
     return std::to_chars(p, end, v, std::chars_format::fixed, 6).ptr;
 }
 
+// "%f" of a FLOAT, exactly as printf prints it, without going through a general double formatter: the value is
+// m * 2^e with a 24-bit m, so round(value * 10^6) is one 64-bit product, one shift and a round-half-to-even on the exact
+// remainder (ties do occur: 1/128 = 0.0078125).  Values of 2^40 and more, NaN and infinities take the general path.
+inline char *put_f32(char *p, char *end, float vf)
+{
+    uint32_t u;
+    std::memcpy(&u, &vf, 4);
+    const uint32_t ex = (u >> 23) & 0xffu;
+    if (ex >= 127 + 40) return put_f(p, end, (double)vf);
+    uint64_t m = u & 0x7fffffu;
+    int e;
+    if (ex == 0) {
+        e = -149; // denormal (or zero)
+    } else {
+        m |= 0x800000u;
+        e = (int)ex - 150;
+    }
+    uint64_t q;
+    const uint64_t P = m * 1000000ull; // < 2^44
+    if (e >= 0) {
+        q = P << e; // e <= 16 here: < 2^60
+    } else {
+        const int sh = -e;
+        if (sh >= 64) {
+            q = 0;
+        } else {
+            q = P >> sh;
+            const uint64_t rem = P & ((1ull << sh) - 1), half = 1ull << (sh - 1);
+            if (rem > half || (rem == half && (q & 1))) ++q;
+        }
+    }
+    if (u >> 31) *p++ = '-';
+    const uint64_t ip = q / 1000000ull;
+    uint32_t fp = (uint32_t)(q % 1000000ull);
+    p = std::to_chars(p, end, ip).ptr;
+    *p++ = '.';
+    for (int i = 5; i >= 0; --i) {
+        p[i] = (char)('0' + fp % 10);
+        fp /= 10;
+    }
+    return p + 6;
+}
+
 // rows [r0, r1) formatted into p; returns the end
 char *format_rows(char *p, char *end, const float *rows, int r0, int r1, int width, int first_frame, long double t0, long double dt)
 {
@@ -175,7 +237,7 @@ char *format_rows(char *p, char *end, const float *rows, int r0, int r1, int wid
         *p++ = '|';
         for (int i = 0; i < width; ++i) {
             *p++ = ' ';
-            p = put_f(p, end, (double)rows[(size_t)width * f + i]);
+            p = put_f32(p, end, rows[(size_t)width * f + i]);
             *p++ = ' ';
             *p++ = '|';
         }
@@ -211,6 +273,8 @@ void write_rows(FILE *out, const float *rows, int n, int width, int first_frame,
 // --timing: wall time per phase, summed over the files of all workers (dev aid; printed at exit)
 struct Timing {
     std::atomic<long long> wait_read{0}, prep{0}, device{0}, write{0}, files{0};
+    std::atomic<long long> prep_wall{0}, write_wall{0}, wait_write{0}, batches{0}; // batched mode: wall time of the stages
+    std::atomic<long long> t_main{0}, t_created{0}, t_loop_end{0}, t_destroyed{0};  // process milestones (last worker to pass)
     bool on = false;
 } g_time;
 inline long long now_ns()
@@ -327,6 +391,130 @@ void process_file(MfccHip &param, const Options &o, const Wav &w, const std::str
     std::printf("%s: %d frames x %d\n", in.c_str(), total, width);
 }
 
+// ---- batches of whole files -----------------------------------------------------------------------------------------
+struct Pinned { // page-locked buffer (DMA straight from / to it), grown on demand
+    void *p = nullptr;
+    size_t bytes = 0;
+    void *get(size_t need)
+    {
+        if (need > bytes) {
+            mfx_free_pinned(p);
+            bytes = need + need / 4;
+            p = mfx_alloc_pinned(bytes);
+            if (!p) throw std::runtime_error("can't allocate pinned host memory");
+        }
+        return p;
+    }
+    ~Pinned() { mfx_free_pinned(p); }
+};
+
+template <class F>
+void parallel_for(size_t n, int threads, F fn)
+{
+    std::atomic<size_t> next{0};
+    auto body = [&](int t) { // t = helper index: callers keep per-helper scratch
+        for (size_t i; (i = next.fetch_add(1)) < n;) fn(i, t);
+    };
+    const int T = (int)std::min<size_t>((size_t)std::max(threads, 1), n);
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(body, t);
+    body(0);
+    for (auto &x : th) x.join();
+}
+
+struct BatchItem {
+    size_t file = 0;            // index of the (input, output) pair
+    std::vector<int16_t> mono;  // downmixed samples
+    std::string error;          // reading / checking failed
+    bool stream = false;        // not batchable: goes through the per-file loop
+    Wav wav;                    // kept for the per-file loop
+    long long off = 0, len = 0, row0 = 0, frames = 0;
+};
+
+struct Batch {
+    std::vector<BatchItem> items;
+    Pinned pcm, rows;
+    long long samples = 0, total_rows = 0;
+    int width = 0;
+};
+
+// Claims files from the shared queue until the batch holds `cap_samples`, reads and downmixes them (io threads) and
+// packs the batchable ones back to back (even offsets: aligned 32-bit loads) into the pinned PCM buffer.
+bool prepare_batch(Batch &b, const Options &o, const std::vector<std::string> &files, std::atomic<size_t> &next, float sr,
+                   long long cap_samples, int limit, int W, int S, int D)
+{
+    struct WallTimer {
+        long long t0 = g_time.on ? now_ns() : 0;
+        ~WallTimer()
+        {
+            if (g_time.on) g_time.prep_wall += now_ns() - t0;
+        }
+    } wall_timer;
+    b.items.clear();
+    b.samples = 0;
+    // file sizes bound the sample counts before anything is read: claim while the batch has room
+    long long claimed = 0;
+    while (claimed < cap_samples && b.items.size() < 4096) {
+        const size_t i = next.fetch_add(1);
+        if (2 * i + 1 >= files.size()) break;
+        BatchItem it;
+        it.file = i;
+        b.items.push_back(std::move(it));
+        FILE *f = std::fopen(files[2 * i].c_str(), "rb");
+        long sz = 0;
+        if (f) {
+            std::fseek(f, 0, SEEK_END);
+            sz = std::ftell(f);
+            std::fclose(f);
+        }
+        claimed += std::max(sz, 0L) / 2;
+    }
+    if (b.items.empty()) return false;
+    const bool sweep = o.alpha_max - o.alpha_min >= o.alpha_step;
+    parallel_for(b.items.size(), o.io_threads, [&](size_t k, int) {
+        BatchItem &it = b.items[k];
+        try {
+            it.wav = read_wav(files[2 * it.file]);
+            if ((float)it.wav.sample_rate != sr) throw std::runtime_error("File \"" + files[2 * it.file] + "\" has incorrect sample rate");
+            const size_t n = it.wav.pcm.size() / it.wav.channels;
+            const long long T = n >= (size_t)W ? (long long)((n - (size_t)(W - S)) / (size_t)S) : 0;
+            // the per-file loop keeps: files of more than one block, files too short for the deltas' context (the
+            // reference refuses or mangles them: same messages from the same code), alpha sweeps
+            it.stream = sweep || n > (size_t)limit || T < 2 * D + 1;
+            if (!it.stream) {
+                it.mono.resize(n);
+                const int ch = it.wav.channels;
+                for (size_t s2 = 0; s2 < n; ++s2)
+                    it.mono[s2] = ch >= 2 ? (int16_t)(((int)it.wav.pcm[s2 * ch] + (int)it.wav.pcm[s2 * ch + 1]) >> 1) : it.wav.pcm[s2 * ch];
+                it.wav.pcm.clear();
+                it.wav.pcm.shrink_to_fit();
+                it.len = (long long)n;
+                it.frames = T;
+            }
+        } catch (const std::exception &e) {
+            it.error = e.what();
+        }
+    });
+    long long pos = 0;
+    for (BatchItem &it : b.items)
+        if (it.error.empty() && !it.stream) {
+            it.off = pos;
+            pos += it.len + (it.len & 1);
+        }
+    b.samples = pos;
+    if (pos > 0) {
+        int16_t *dst = (int16_t *)b.pcm.get((size_t)(pos + 8) * sizeof(int16_t));
+        parallel_for(b.items.size(), o.io_threads, [&](size_t k, int) {
+            BatchItem &it = b.items[k];
+            if (!it.error.empty() || it.stream) return;
+            std::memcpy(dst + it.off, it.mono.data(), (size_t)it.len * sizeof(int16_t));
+            if (it.len & 1) dst[it.off + it.len] = 0;
+            std::vector<int16_t>().swap(it.mono);
+        });
+    }
+    return true;
+}
+
 // One worker of the reference's file queue (process_files_worker over the shared std::list,
 // ASR_OCL.cpp:109-338,340-368): its own extractor on its own device, files drawn from a shared index
 // until the queue is empty.  The reference runs its workers one after another (:365-366); these run
@@ -338,11 +526,143 @@ void worker(const Options &o, int device, float sr, const std::vector<std::strin
         const long W = (long)(sr * o.window_ms * 1e-3), S = (long)(sr * o.shift_ms * 1e-3);
         MfccHip param(o.sample_limit, (int)W, (int)S, o.banks, sr, o.low, o.high, o.ceps, o.c0, o.lift,
                       (Normalizer::norm_t)o.norm, (ParamBase::dyn_t)o.dyn, o.l1, o.l2, o.norm_after_dyn, device,
-                      o.bug_compat);
+                      o.bug_compat, o.batch_mb > 0 ? MFX_ENGINE_STREAM_KERNELS : 0);
+        if (g_time.on) g_time.t_created = now_ns();
+        struct LoopEnd { // (runs before the extractor is destroyed: declared after it)
+            ~LoopEnd()
+            {
+                if (g_time.on) g_time.t_loop_end = now_ns();
+            }
+        } loop_end;
         std::vector<float> window((size_t)W);
         for (long i = 0; i < W; ++i) // ASR_OCL.cpp:149-151
             window[i] = (float)(0.56f - 0.46f * std::cos((2.0f * M_PI * i) / W)) / 32768.f;
         param.set_window(window.data());
+        Scratch sc;
+        if (o.batch_mb > 0) {
+            // ---- batches of whole files: read batch k + 1 and write batch k - 1 (helper threads) beside the device calls
+            // of batch k (this thread)
+            const int limit = param.get_input_buffer_size(), width = param.get_output_data_width();
+            const int D = o.dyn == 0 ? 0 : o.dyn == 1 ? o.l1 : o.l1 + o.l2, cols = width / (1 + o.dyn);
+            const long long cap = (long long)o.batch_mb * 1024 * 1024 / 2;
+            const long double dt = o.bug_compat ? (long double)(o.shift_ms / sr) : o.shift_ms / 1000.0L;
+            const long double t0 = o.bug_compat ? (long double)(0.5f * o.window_ms / sr) : 0.5L * o.window_ms / 1000.0L;
+            Batch slots[2];
+            std::vector<std::vector<char>> text_bufs((size_t)std::max(o.io_threads, 1));
+            auto write_batch = [&](Batch *b) {
+                const long long tww = g_time.on ? now_ns() : 0;
+                const float *rows = (const float *)b->rows.p;
+                parallel_for(b->items.size(), o.io_threads, [&](size_t k, int t) {
+                    const BatchItem &it = b->items[k];
+                    if (!it.error.empty() || it.stream) return;
+                    try {
+                        const long long tw0 = g_time.on ? now_ns() : 0;
+                        const std::string &name = files[2 * it.file + 1];
+                        FILE *fo = std::fopen(name.c_str(), o.htk ? "wb" : "w");
+                        if (!fo) throw std::runtime_error("Can't create output file: " + name);
+                        std::vector<char> &text = text_bufs[(size_t)t]; // (grown once per helper, not per file)
+                        const float *r = rows + (size_t)it.row0 * b->width;
+                        if (o.htk) {
+                            write_htk_header(fo, (uint32_t)it.frames, o, b->width);
+                            write_rows_htk(fo, r, (int)it.frames, b->width, text);
+                        } else {
+                            write_rows(fo, r, (int)it.frames, b->width, 0, t0, dt, text, 1);
+                        }
+                        std::fclose(fo);
+                        if (g_time.on) {
+                            g_time.write += now_ns() - tw0;
+                            ++g_time.files;
+                        }
+                    } catch (const std::exception &e) {
+                        std::fprintf(stderr, "Exception caught %s\n", e.what());
+                        ++failures;
+                    }
+                });
+                std::string log;
+                for (const BatchItem &it : b->items)
+                    if (it.error.empty() && !it.stream)
+                        log += files[2 * it.file] + ": " + std::to_string(it.frames) + " frames x " + std::to_string(b->width) + "\n";
+                {
+                    static std::mutex print_lock;
+                    std::lock_guard<std::mutex> g(print_lock);
+                    std::fputs(log.c_str(), stdout);
+                }
+                if (g_time.on) g_time.write_wall += now_ns() - tww;
+            };
+            int cur = 0;
+            std::future<bool> prep = std::async(std::launch::async, [&, cur] {
+                return prepare_batch(slots[cur], o, files, next, sr, cap, limit, (int)W, (int)S, D);
+            });
+            std::future<void> writer;
+            for (;;) {
+                const long long tw0 = g_time.on ? now_ns() : 0;
+                const bool have = prep.get();
+                if (g_time.on) g_time.wait_read += now_ns() - tw0;
+                if (!have) break;
+                Batch &b = slots[cur];
+                const int nxt = cur ^ 1;
+                {
+                    const long long t_ww = g_time.on ? now_ns() : 0;
+                    if (writer.valid()) writer.get(); // the other slot's rows are on disk: it may be refilled
+                    if (g_time.on) g_time.wait_write += now_ns() - t_ww, ++g_time.batches;
+                }
+                prep = std::async(std::launch::async, [&, nxt] {
+                    return prepare_batch(slots[nxt], o, files, next, sr, cap, limit, (int)W, (int)S, D);
+                });
+                for (const BatchItem &it : b.items)
+                    if (!it.error.empty()) { // a bad file does not stop the queue
+                        std::fprintf(stderr, "Exception caught %s\n", it.error.c_str());
+                        ++failures;
+                    }
+                // ---- device: one plan + one run for all batchable files
+                std::vector<long long> off, len, row0;
+                std::vector<BatchItem *> in_batch;
+                for (BatchItem &it : b.items)
+                    if (it.error.empty() && !it.stream) {
+                        off.push_back(it.off);
+                        len.push_back(it.len);
+                        in_batch.push_back(&it);
+                    }
+                b.width = width;
+                b.total_rows = 0;
+                if (!in_batch.empty()) {
+                    const long long td0 = g_time.on ? now_ns() : 0;
+                    row0.resize(in_batch.size());
+                    b.total_rows = param.batch_plan((int)in_batch.size(), off.data(), len.data(), row0.data());
+                    float *rows = (float *)b.rows.get((size_t)std::max<long long>(b.total_rows, 1) * width * sizeof(float));
+                    param.batch_run_host((const short *)b.pcm.p, b.samples, rows);
+                    for (size_t k = 0; k < in_batch.size(); ++k) {
+                        BatchItem &it = *in_batch[k];
+                        it.row0 = row0[k];
+                        if (it.frames != param.batch_frames(it.len)) throw std::runtime_error("frame count mismatch");
+                        // The reference's flush after exactly one set_input reads its D static rows D rows early (B1,
+                        // mfcccpu.cpp:439 + segmentercpu.cpp:97-106): rows T - D .. T - 1 repeat the statics of rows
+                        // T - 2 D .. T - D - 1 (deltas unaffected).  The batch entries deliver the correct rows; the
+                        // per-file loop this replaces reproduces the reference when --bug-compat is on, so do we.
+                        if (o.bug_compat && D > 0)
+                            for (int i = 0; i < D; ++i)
+                                std::memcpy(rows + (size_t)(it.row0 + it.frames - D + i) * width,
+                                            rows + (size_t)(it.row0 + it.frames - 2 * D + i) * width, (size_t)cols * sizeof(float));
+                    }
+                    if (g_time.on) g_time.device += now_ns() - td0;
+                }
+                // ---- files that need the per-file loop (longer than one block, too short, alpha sweeps)
+                for (BatchItem &it : b.items)
+                    if (it.error.empty() && it.stream) {
+                        try {
+                            process_file(param, o, it.wav, files[2 * it.file], files[2 * it.file + 1], sr, sc);
+                        } catch (const std::exception &e) {
+                            std::fprintf(stderr, "Exception caught %s\n", e.what());
+                            ++failures;
+                        }
+                    }
+                writer = std::async(std::launch::async, write_batch, &b);
+                cur = nxt;
+            }
+            if (writer.valid()) writer.get();
+            return;
+        }
+        // The worker's next file is claimed and read (its own thread) while the current one is on the GPU.
         // The worker's next file is claimed and read (its own thread) while the current one is on the GPU.
         struct Pending {
             size_t i;
@@ -355,7 +675,6 @@ void worker(const Options &o, int device, float sr, const std::vector<std::strin
             return true;
         };
         Pending cur, nxt;
-        Scratch sc;
         bool have = claim(cur);
         while (have) {
             const bool have_next = claim(nxt);
@@ -381,6 +700,7 @@ void worker(const Options &o, int device, float sr, const std::vector<std::strin
 
 int main(int argc, char **argv)
 {
+    g_time.t_main = now_ns();
     Options o;
     std::vector<std::string> files;
     for (int i = 1; i < argc; ++i) {
@@ -422,11 +742,44 @@ int main(int argc, char **argv)
         else if (a == "--htk") o.htk = true;
         else if (a == "--timing") g_time.on = true;
         else if (a == "--format-threads") o.format_threads = std::max(1, std::atoi(val()));
+        else if (a == "--batch-mb") o.batch_mb = std::max(0, std::atoi(val()));
+        else if (a == "--io-threads") o.io_threads = std::max(1, std::atoi(val()));
+        else if (a == "--selftest-format") { // put_f32 against printf("%f") on n random bit patterns + the known hard cases
+            const long n = std::atol(val());
+            uint64_t st = 0x9E3779B97F4A7C15ull;
+            long bad = 0;
+            auto check = [&](float v) {
+                char a1[128], a2[128];
+                char *e1 = put_f32(a1, a1 + sizeof(a1), v);
+                *e1 = 0;
+                std::snprintf(a2, sizeof(a2), "%f", (double)v);
+                if (std::strcmp(a1, a2) != 0 && ++bad < 10) std::fprintf(stderr, "put_f32 mismatch: %s vs %s\n", a1, a2);
+            };
+            const float hard[] = {0.f, -0.f, 1.f / 128, -1.f / 128, 0.5e-6f, 1.5e-6f, 2.5e-6f, 1e-10f, -1e-10f, 1e-45f, 123456.789f,
+                                  -69.07755f, 0.9999995f, 0.99999994f, 9.9999995f, 16777216.f, 1e12f, 1.0995116e12f, 3.4e38f,
+                                  -3.4e38f, 0.0078125f, 0.0234375f, 1.0000005f, 4194304.5f, 8388607.5f};
+            for (float v : hard) check(v);
+            check(std::nanf(""));
+            check(INFINITY);
+            check(-INFINITY);
+            for (long i = 0; i < n; ++i) {
+                st ^= st << 13, st ^= st >> 7, st ^= st << 17; // xorshift64
+                uint32_t b = (uint32_t)(st >> 16);
+                float v;
+                std::memcpy(&v, &b, 4);
+                check(v);
+                // and values in the range features actually take
+                check((float)((double)(int32_t)(st >> 33) * 1e-7));
+            }
+            std::printf("put_f32 selftest: %ld mismatches\n", bad);
+            return bad ? 1 : 0;
+        }
         else if (a == "--help") {
             std::printf("afet_hip [--window-size ms] [--shift ms] [--banks n] [--ceps n] [--c0 0|1] [--norm 0..3]\n"
                         "         [--dyn 0..2] [--l1 n] [--l2 n] [--low-freq hz] [--high-freq hz] [--lift-coef x]\n"
                         "         [--norm-after-dyn 0|1] [--alpha a | --alpha-min a --alpha-max b --alpha-step s]\n"
                         "         [--sample-limit n] [--dev n | --devs a,b,...] [--bug-compat 0|1] [--htk]  in.wav out.txt [...]\n"
+                        "         [--batch-mb n (PCM per batch of whole files; 0 = per-file loop)] [--io-threads n]\n"
                         "  --devs: one worker per listed GPU, files dealt from a shared queue\n"
                         "  inputs: RIFF/WAVE or NIST SPHERE, 16-bit PCM; output: the reference's text rows, or HTK binary\n");
             return 0;
@@ -450,11 +803,20 @@ int main(int argc, char **argv)
             for (int d : o.devices) pool.emplace_back(worker, std::cref(o), d, sr, std::cref(files), std::ref(next), std::ref(failures));
             for (auto &t : pool) t.join();
         }
+        if (g_time.on) g_time.t_destroyed = now_ns();
         if (g_time.on && g_time.files > 0) {
             const double n = (double)g_time.files.load();
+            std::fprintf(stderr, "process milestones (ms): start -> extractor created %.1f, file loop %.1f (%.0f files/s inside the loop), "
+                                 "extractor destroyed %.1f\n", (g_time.t_created - g_time.t_main) / 1e6,
+                         (g_time.t_loop_end - g_time.t_created) / 1e6, n / ((g_time.t_loop_end - g_time.t_created) / 1e9),
+                         (g_time.t_destroyed - g_time.t_loop_end) / 1e6);
             std::fprintf(stderr, "timing per file (us): waiting for the reader %.0f, host preparation %.0f, device calls %.0f, "
-                                 "formatting + writing %.0f\n", g_time.wait_read / n / 1e3, g_time.prep / n / 1e3,
+                                 "formatting + writing %.0f", g_time.wait_read / n / 1e3, g_time.prep / n / 1e3,
                          g_time.device / n / 1e3, g_time.write / n / 1e3);
+            if (g_time.batches > 0)
+                std::fprintf(stderr, "; %lld batches, stage wall time per file: read + pack %.0f, write %.0f, waiting for the writer %.0f",
+                             g_time.batches.load(), g_time.prep_wall / n / 1e3, g_time.write_wall / n / 1e3, g_time.wait_write / n / 1e3);
+            std::fprintf(stderr, "\n");
         }
         return failures.load() ? 1 : 0;
     } catch (const std::exception &e) {

@@ -85,7 +85,7 @@ public:
     MfccHip(int input_buffer_size, int window_size, int shift, int num_banks, float sample_rate, float low_freq,
             float high_freq, int ceps_len, bool want_c0, float lift_coef,
             Normalizer::norm_t norm = Normalizer::NORM_NONE, dyn_t dyn = DYN_NONE, int delta_l1 = 1,
-            int delta_l2 = 1, bool norm_after_dyn = true, int hip_device = 0, bool bug_compat = true);
+            int delta_l2 = 1, bool norm_after_dyn = true, int hip_device = 0, bool bug_compat = true, int engine = 0);
     ~MfccHip() override;
     MfccHip(const MfccHip &) = delete;
     MfccHip &operator=(const MfccHip &) = delete;
@@ -101,6 +101,12 @@ public:
     // one call); block i of the result is read with get_output_data_alpha(i, ...)
     void apply_alphas(const float *alphas, int n_alpha);
     void get_output_data_alpha(int alpha_index, float *data_out, int window_count);
+
+    // Many files in one launch sequence (mfx_batch_plan / mfx_batch_run_host): utterance u = samples [offsets[u],
+    // offsets[u] + lengths[u]) of one PCM array, its rows start at out_rows[u]; returns the total number of rows
+    long long batch_plan(int n_utt, const long long *offsets, const long long *lengths, long long *out_rows);
+    void batch_run_host(const short *pcm, long long samples_total, float *out);
+    long long batch_frames(long long samples) const;
 
     // upper bound on the rows one set_input()/flush() can deliver (the reference's own bound,
     // estimated_window_count(get_input_buffer_size()), can be exceeded: SURVEY B6)

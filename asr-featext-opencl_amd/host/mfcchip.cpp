@@ -52,7 +52,7 @@ int MfccBase::get_output_data_width() const
 MfccHip::MfccHip(int input_buffer_size, int window_size, int shift, int num_banks, float sample_rate,
                  float low_freq, float high_freq, int ceps_len, bool want_c0, float lift_coef,
                  Normalizer::norm_t norm, dyn_t dyn, int delta_l1, int delta_l2, bool norm_after_dyn, int hip_device,
-                 bool bug_compat)
+                 bool bug_compat, int engine)
     : MfccBase(input_buffer_size, window_size, shift, num_banks, sample_rate, low_freq, high_freq, ceps_len, want_c0,
                lift_coef, norm, dyn, delta_l1, delta_l2, norm_after_dyn),
       m_handle(nullptr)
@@ -74,6 +74,7 @@ MfccHip::MfccHip(int input_buffer_size, int window_size, int shift, int num_bank
     cfg.delta_l2 = delta_l2;
     cfg.norm_after_dyn = norm_after_dyn ? 1 : 0;
     cfg.bug_compat = bug_compat ? 1 : 0;
+    cfg.engine = engine;
     const int rc = mfx_create(&cfg, hip_device, &m_handle);
     if (rc != MFX_OK) throw std::runtime_error(std::string("MfccHip: ") + mfx_status_string(rc));
 }
@@ -128,3 +129,18 @@ void MfccHip::get_output_data_alpha(int alpha_index, float *data_out, int window
 }
 
 int MfccHip::max_frames_out() const { return mfx_max_frames_out(m_handle); }
+
+long long MfccHip::batch_plan(int n_utt, const long long *offsets, const long long *lengths, long long *out_rows)
+{
+    static_assert(sizeof(long long) == sizeof(int64_t), "64-bit long long");
+    int64_t total = 0;
+    check(mfx_batch_plan(m_handle, n_utt, (const int64_t *)offsets, (const int64_t *)lengths, (int64_t *)out_rows, &total));
+    return (long long)total;
+}
+
+void MfccHip::batch_run_host(const short *pcm, long long samples_total, float *out)
+{
+    check(mfx_batch_run_host(m_handle, pcm, (int64_t)samples_total, out));
+}
+
+long long MfccHip::batch_frames(long long samples) const { return (long long)mfx_batch_frames(m_handle, (int64_t)samples); }

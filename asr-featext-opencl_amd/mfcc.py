@@ -60,6 +60,7 @@ EXPORTED_SYMBOLS = (
     "mfx_host_dct_mfma_operands",
     "mfx_estimated_window_count", "mfx_max_frames_out", "mfx_fft_size",
     "mfx_batch_frames", "mfx_batch_plan", "mfx_batch_run_device", "mfx_batch_run_host", "mfx_batch_overlap",
+    "mfx_alloc_pinned", "mfx_free_pinned",
     "mfx_set_stream", "mfx_synchronize", "mfx_profile_enable", "mfx_profile_read",
     "mfx_dominant_kernel_name", "mfx_debug_read",
     "mfx_host_mel_table", "mfx_host_dct_matrix", "mfx_host_frame_count",
@@ -206,7 +207,7 @@ def reference_window(window_size):
     return (inner.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
 
 
-ENGINE_NO_FRONT1024, ENGINE_FUSE_DELTA, ENGINE_NO_FRONT2048 = 1, 2, 4     # mfx_config.engine bits (include/mfx.h)
+ENGINE_NO_FRONT1024, ENGINE_FUSE_DELTA, ENGINE_NO_FRONT2048, ENGINE_STREAM_KERNELS = 1, 2, 4, 8     # mfx_config.engine bits (include/mfx.h)
 
 
 class MfccHip:

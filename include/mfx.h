@@ -20,6 +20,7 @@
 #ifndef MFX_H
 #define MFX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -89,6 +90,10 @@ typedef struct mfx_config {
 /* mfx_config.engine bits */
 #define MFX_ENGINE_NO_FRONT1024 1 /* 1024-point short-window configurations stay on the generic long-transform kernel  */
 #define MFX_ENGINE_NO_FRONT2048 4 /* 2048-point short-window configurations stay on the generic long-transform kernel  */
+#define MFX_ENGINE_STREAM_KERNELS 8 /* batch entries run the streaming interface's kernels (spectrum through HBM, then the
+                                      mel / DCT kernel) instead of the fused front ends: the rows are then the SAME BITS
+                                      that set_input / apply / get_output_data deliver for a file consumed as one block
+                                      (the fused kernels agree with them to float32 rounding, ~1e-6 of scale)           */
 #define MFX_ENGINE_FUSE_DELTA 2   /* 512-point batch path: delta / delta-delta computed by a wave of the front-end kernel
                                      instead of the separate delta kernel (slower on MI355X)        */
 
@@ -176,6 +181,11 @@ int mfx_batch_overlap(mfx_handle *h, int enable);
 
 /* Convenience: same, from/to HOST buffers (pinned staging + H2D, run, D2H, synchronises). */
 int mfx_batch_run_host(mfx_handle *h, const int16_t *pcm, int64_t pcm_samples_total, float *out);
+
+/* Page-locked host memory for the caller's PCM / feature buffers (mfx_batch_run_host and the streaming entries DMA
+ * straight from / to such buffers; pageable ones go through the handle's staging).  NULL on failure. */
+void *mfx_alloc_pinned(size_t bytes);
+void mfx_free_pinned(void *p);
 
 /* ---- stream / timing plumbing ---- */
 /* Use an existing hipStream_t (e.g. torch's current stream) instead of the handle's own. */

@@ -488,3 +488,14 @@ def test_two_rank_gloo_strong_scaling_job(tmp_path):
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
     assert r.stdout.count("ok") >= 2
+
+
+def test_cpp_driver_float_formatter_matches_printf():
+    """afet_hip formats feature values with its own exact "%f" for floats (one 64-bit product, a shift and round-half-to-even
+    on the exact remainder) instead of a general double formatter: it must print what printf("%f") prints -- the
+    reference's text (ASR_OCL.cpp:254-257) -- for random bit patterns, ties (1/128), denormals, signed zeros, NaN / inf."""
+    exe = os.path.join(ROOT, "asr-featext-opencl_amd", "host", "afet_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    r = subprocess.run([exe, "--selftest-format", "300000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout, r.stderr)

@@ -1491,3 +1491,40 @@ def test_c5_full_size_properties(pkg, orc):
         mono = ((x[:, 0] + x[:, 1]) >> 1).astype(np.int16)
         want = orc.run_utterance(cfg, mono, w, bug_compat=False)
         assert_close(out[rows[u]:rows[u] + T].cpu().numpy(), want, "C5 utt %d" % u, groups=3)
+
+
+@pytest.mark.parametrize("opts", [
+    ["--banks", "26", "--ceps", "13", "--c0", "0", "--norm", "0", "--dyn", "2", "--l1", "3", "--l2", "3"],
+    [],                                                                   # the reference main()'s defaults: 15 / 12 + c0 / CVN
+    ["--banks", "40", "--ceps", "13", "--norm", "2", "--dyn", "2", "--bug-compat", "0"],
+    ["--banks", "24", "--ceps", "0", "--norm", "1", "--dyn", "1", "--l1", "2", "--norm-after-dyn", "0"],
+    ["--banks", "26", "--ceps", "12", "--norm", "3", "--dyn", "2", "--htk"],
+])
+def test_cpp_driver_batches_are_byte_identical_to_the_per_file_loop(tmp_path, opts):
+    """afet_hip drains its file queue into batches (one mfx_batch_plan + mfx_batch_run_host per batch, the extractor on the
+    streaming interface's kernels, the reference's single-block flush behaviour B1 applied to the rows): every output file
+    must be byte-identical to what the per-file loop (--batch-mb 0: set_input / apply / get_output_data / flush per file,
+    ASR_OCL.cpp:227-301) writes -- text and HTK, normalisation on and off, bug-compat on and off, mixed with files that
+    stay on the loop (longer than --sample-limit)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "asr-featext-opencl_amd", "host", "afet_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    srcs = ["a0001.wav", "a1.wav", "sample1_sphere.wav", "sample1_riff.wav", "a0001.wav", "a1.wav", "a0001.wav"] * 3
+
+    def run(tag, extra):
+        args = []
+        for i, s_ in enumerate(srcs):
+            args += [os.path.join(GOLDEN, s_), str(tmp_path / ("%s_%d.out" % (tag, i)))]
+        subprocess.check_call([exe] + opts + extra + args, stdout=subprocess.DEVNULL)
+        return [open(tmp_path / ("%s_%d.out" % (tag, i)), "rb").read() for i in range(len(srcs))]
+
+    loop = run("loop", ["--batch-mb", "0"])
+    batch = run("batch", [])
+    small = run("small", ["--batch-mb", "1", "--io-threads", "3"])          # several batches, double buffering exercised
+    mixed = run("mixed", ["--sample-limit", "100000"])                      # a0001 (114 000 samples) stays on the loop
+    mixed_loop = run("mixedloop", ["--sample-limit", "100000", "--batch-mb", "0"])
+    assert all(len(t) > 1000 for t in loop)
+    assert batch == loop and small == loop
+    assert mixed == mixed_loop

@@ -16,4 +16,10 @@ for mode in "" "--htk"; do
   done
 done
 md5sum $D/o1 $D/o$N | cut -c1-32 | tr '\n' ' '; echo
+# the per-file loop (--batch-mb 0) for comparison: same bytes, round-2 speed
+for mode in "" "--htk"; do
+  s=$(date +%s.%N); $EXE $OPT $mode $TIMING --batch-mb 0 --devs 0 $args > /dev/null 2> $D/err; rc=$?; e=$(date +%s.%N)
+  tail -1 $D/err; python3 -c "print('%-6s per-file loop, 1 worker rc %d: %7.1f files/s' % ('$mode' or 'text', $rc, $N / ($e - $s)))"
+done
+md5sum $D/o1 $D/o$N | cut -c1-32 | tr '\n' ' '; echo
 rm -rf $D
