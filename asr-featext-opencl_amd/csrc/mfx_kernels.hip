@@ -2449,8 +2449,9 @@ int front_reg_waves(const FrontParams &p, bool fused)
             best = nw;
         }
     }
-    const char *e = std::getenv("MFX_REG_NW"); // dev override
-    if (e && std::atoi(e) >= 4 && std::atoi(e) <= top) best = std::atoi(e);
+#ifdef MFX_REG_NW // dev builds only (tools/build_variant.sh): a fixed wave count for the A/B of block shapes
+    if (MFX_REG_NW >= 4 && MFX_REG_NW <= top) best = MFX_REG_NW;
+#endif
     return best;
 }
 

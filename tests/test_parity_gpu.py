@@ -1528,3 +1528,37 @@ def test_cpp_driver_batches_are_byte_identical_to_the_per_file_loop(tmp_path, op
     assert all(len(t) > 1000 for t in loop)
     assert batch == loop and small == loop
     assert mixed == mixed_loop
+
+
+def test_cpp_driver_multichannel_downmix_policy(orc, a0001, tmp_path):
+    """ONE multi-channel policy across the product, pinned here so it cannot drift: mono = (L + R) >> 1 in integer
+    arithmetic over the FIRST TWO channels (the batch kernels' channels = 2 downmix; further channels are ignored).  The
+    reference itself has no downmix -- it reads `frames` interleaved shorts into a mono-sized buffer, ASR_OCL.cpp:229-231 --
+    and ships no multi-channel fixture: this is a deliberate deviation, parity unpinned."""
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "asr-featext-opencl_amd", "host", "afet_hip")
+    n = 48000
+    left = a0001[:n].astype(np.int32)
+    right = np.roll(a0001[:n], 777).astype(np.int32) // 2
+    third = np.full(n, 12345, np.int32)                      # a third channel that must not leak into the result
+
+    def wav(path, chans):
+        data = np.stack(chans, axis=1).astype("<i2").tobytes()
+        hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack(
+            "<IHHIIHH", 16, 1, len(chans), 16000, 16000 * 2 * len(chans), 2 * len(chans), 16) + b"data" + struct.pack("<I", len(data))
+        open(path, "wb").write(hdr + data)
+
+    wav(tmp_path / "mono.wav", [(left + right) >> 1])
+    wav(tmp_path / "stereo.wav", [left, right])
+    wav(tmp_path / "three.wav", [left, right, third])
+    opts = ["--banks", "26", "--ceps", "13", "--c0", "0", "--norm", "0", "--dyn", "2"]
+    for mode in ([], ["--batch-mb", "0"]):
+        args = []
+        for name in ("mono", "stereo", "three"):
+            args += [str(tmp_path / (name + ".wav")), str(tmp_path / (name + ".txt"))]
+        subprocess.check_call([exe] + opts + mode + args, stdout=subprocess.DEVNULL)
+        ref = open(tmp_path / "mono.txt").read()
+        assert len(ref) > 10000
+        assert open(tmp_path / "stereo.txt").read() == ref and open(tmp_path / "three.txt").read() == ref
