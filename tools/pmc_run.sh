@@ -23,7 +23,7 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
         if "mfx::" not in k: continue
-        short = next((n for n in ("k_front2048", "k_front512", "k_front1024", "k_front_reg", "k_front_wave", "k_delta16", "k_delta", "k_melcep", "k_norm") if n in k), k[:40])
+        short = next((n for n in ("k_front2048", "k_front512", "k_front1024", "k_front_reg", "k_front_wave", "k_delta16", "k_delta", "k_melcep", "k_norm_stats", "k_norm_finalize", "k_norm_apply") if n in k), k[:40])
         agg[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 json.dump(res, open(out + "/pmc_summary.json", "w"), indent=1, sort_keys=True)
