@@ -4,8 +4,10 @@
  *
  * Arithmetic follows the reference's float32 expression order.  Where the reference calls an
  * unqualified libm name on a float (log/exp/sin/cos/atan/sqrt in mfcccpu.cpp:21-22,36,203,212)
- * the float overload is used here, which is what the reference's own toolchain (MSVC, global
- * <cmath> overloads) resolves to.
+ * the float overload is used by default, which is what the reference's own toolchain (MSVC, global
+ * <cmath> overloads) resolves to; orc_set_libm_binding(o, 1) selects the C double functions instead,
+ * which is how g++ compiles those lines -- and under which this file is bit-identical to the
+ * reference's compiled mfcccpu.cpp (oracle/_ref/libref_mfcccpu.so, tests/test_ref_mfcccpu.py).
  */
 #include "mfcc_oracle.h"
 

@@ -9,12 +9,20 @@
  *   segmentercpu.cpp, deltacpu.cpp, normalizercpu.cpp, parambase.cpp, mfccbase.cpp.
  * Each function below cites the reference file:line it follows.
  *
- * PINNING STATUS: "parity unpinned" for the composed FFT -> mel -> log -> DCT result.  The
- * reference holds no golden feature vectors and its CPU path needs libfftw3f, which is absent
- * from this image, so mfcccpu.cpp cannot be built here.  What IS pinned against the real
- * reference objects (oracle/_ref, built from /root/reference in place): the segmenter state
- * machine and framing, the delta regression, the normalizer, frame-count and output-width
- * arithmetic.  The FFT stage is pinned against the DFT definition (numpy float64).
+ * PINNING STATUS: pinned to the reference's own compiled code, function by function.
+ *   - oracle/_ref/libref_stages.so: the reference's parambase / mfccbase / segmentercpu / deltacpu / normalizercpu
+ *     translation units, compiled in place from /root/reference;
+ *   - oracle/_ref/libref_mfcccpu.so (round 3): the reference's mfcccpu.cpp as well -- MfccCpu::refresh_filters, filter, dct,
+ *     do_delta, normalize, apply, get_output_data run as compiled; only its constructor / destructor / fft(), the sole
+ *     users of libfftw3f (absent from this image), are never referenced and are dropped by the linker (--gc-sections; no
+ *     fftwf_* symbol remains, no stand-in for FFTW is written).  See oracle/ref_mfcccpu_shim.cpp.
+ *   With the reference's unqualified libm calls bound as g++ binds them (orc_set_libm_binding(o, 1)) this restatement is
+ *   BIT-IDENTICAL to that library on every case of tests/refcases.py and on a randomised sweep (tests/test_ref_mfcccpu.py);
+ *   under the reference's own toolchain binding (MSVC float overloads, the default here) no filter edge moves and rows
+ *   stay within 5e-6 of the output scale.  The committed vectors are tests/golden/ref_mfcccpu_vectors.npz.
+ *   Not pinned by execution, "by definition" instead: the transform at the FFTW call site (mfcccpu.cpp:114,187-190 -- the
+ *   DFT, checked against numpy float64) and the DCT + lifter matrix block of the constructor (mfcccpu.cpp:118-136, explicit
+ *   sinf / cosf: no toolchain question).
  */
 #ifndef MFCC_ORACLE_H
 #define MFCC_ORACLE_H

@@ -3,9 +3,9 @@
 // Compiled by oracle/Makefile together with the reference's own translation units, which are
 // read in place from /root/reference (never copied):
 //     parambase.cpp mfccbase.cpp segmentercpu.cpp deltacpu.cpp normalizercpu.cpp
-// into oracle/_ref/libref_stages.so.  mfcccpu.cpp is NOT part of it: it needs libfftw3f, which
-// this image does not have ("Oracle").  The shim adds no arithmetic of its own;
-// it only forwards calls so that ctypes can reach the C++ classes.
+// into oracle/_ref/libref_stages.so.  (mfcccpu.cpp has its own door, ref_mfcccpu_shim.cpp ->
+// oracle/_ref/libref_mfcccpu.so, which links it without its FFTW-calling constructor.)  The shim adds
+// no arithmetic of its own; it only forwards calls so that ctypes can reach the C++ classes.
 #include <stdexcept>
 
 #include "deltacpu.h"
