@@ -152,34 +152,70 @@ __host__ __device__ inline int lm_fs4(int nb)
 // association.  Operands come four bands at a time (one 16-byte LDS read, one 16-byte buffer load; B laid out
 // [tile][band / 4][lane][4], bands past the table return 0), software pipelined without branches: the next four bands'
 // operands are requested before the current four instructions issue.
-__device__ __forceinline__ void dct_mfma4(const float *arow, __amdgpu_buffer_rsrc_t rsrc, int table_bytes, int lane, int tile,
-                                          int ks, float (&res)[4])
+// KS > 0: the number of four-band batches is a compile-time constant and the whole ring is unrolled -- every wait is then
+// counted exactly (around a loop's back edge the compiler waits for ALL outstanding loads: the ring would be drained once
+// per turn); KS = 0: a loop over runtime `ks` for the other filterbank sizes.
+template <int KS, int DEPTH>
+__device__ __forceinline__ void dct_mfma4_impl(const float *arow, __amdgpu_buffer_rsrc_t rsrc, int table_bytes, int lane, int tile,
+                                               int ks, float (&res)[4])
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef float v4f __attribute__((ext_vector_type(4)));
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-    float4 ava, avb;
-    u32x4 bva, bvb;
-    auto fetch = [&](u32x4 &bv, float4 &av, int j4) {
-        av = lds_read_b128((const float4 *)(arow + 4 * (j4 < ks ? j4 : 0)));
-        bv = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, j4 < ks ? ((tile * ks + j4) * 1024) : table_bytes, 0);
+    // A ring of DEPTH operand pairs in flight: four instructions are 32 SIMD cycles, an operand load from L1 / L2 takes
+    // 300 - 500 -- with one batch ahead the wave waited out every load (stamps: 84 cycles per instruction).
+    // (DEPTH: 6 in k_front2048 -- 8 spills 37 registers in its stereo build; 3 in k_melcep / k_front_wave, whose
+    // occupancy is set by registers, not LDS)
+    v4f av[DEPTH];
+    u32x4 bv[DEPTH];
+    // (plain 16-byte LDS read: the lds_read_b128 wrapper's register constraint would wait for the data where it is
+    // requested, not where it is used)
+    auto fetch = [&](int slot, int j4) {
+        av[slot] = *(const v4f *)(arow + 4 * (j4 < ks ? j4 : 0));
+        bv[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, j4 < ks ? ((tile * ks + j4) * 1024) : table_bytes, 0);
     };
-    auto mac = [&](const u32x4 &bv, const float4 &av) {
-        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, __uint_as_float(bv[0]), d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, __uint_as_float(bv[1]), d1, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, __uint_as_float(bv[2]), d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, __uint_as_float(bv[3]), d1, 0, 0, 0);
+    auto mac = [&](int slot) {
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[slot][0], __uint_as_float(bv[slot][0]), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[slot][1], __uint_as_float(bv[slot][1]), d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[slot][2], __uint_as_float(bv[slot][2]), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[slot][3], __uint_as_float(bv[slot][3]), d1, 0, 0, 0);
     };
-    fetch(bva, ava, 0);
-    for (int j4 = 0; j4 < ks; j4 += 2) {
-        fetch(bvb, avb, j4 + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mac(bva, ava);
-        fetch(bva, ava, j4 + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mac(bvb, avb);
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) fetch(i, i);
+    if (KS > 0) {
+#pragma unroll
+        for (int j4 = 0; j4 < KS; ++j4) {
+            __builtin_amdgcn_sched_barrier(0);
+            mac(j4 % DEPTH);
+            if (j4 + DEPTH < KS) fetch(j4 % DEPTH, j4 + DEPTH);
+        }
+    } else {
+        for (int j4 = 0; j4 < ks; j4 += DEPTH) {
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i) {
+                __builtin_amdgcn_sched_barrier(0);
+                mac(i);
+                fetch(i, j4 + DEPTH + i);
+            }
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) res[i] = d0[i] + d1[i];
+}
+
+template <int DEPTH>
+__device__ __forceinline__ void dct_mfma4(const float *arow, __amdgpu_buffer_rsrc_t rsrc, int table_bytes, int lane, int tile,
+                                          int ks, float (&res)[4])
+{
+    // the filterbank sizes of the BASELINE configurations (128 / 80 / 40 bands) get the unrolled form
+    if (ks == 32)
+        dct_mfma4_impl<32, DEPTH>(arow, rsrc, table_bytes, lane, tile, ks, res);
+    else if (ks == 20)
+        dct_mfma4_impl<20, DEPTH>(arow, rsrc, table_bytes, lane, tile, ks, res);
+    else if (ks == 10)
+        dct_mfma4_impl<10, DEPTH>(arow, rsrc, table_bytes, lane, tile, ks, res);
+    else
+        dct_mfma4_impl<0, DEPTH>(arow, rsrc, table_bytes, lane, tile, ks, res);
 }
 
 // One frame's mel filterbank on the 64 lanes of a wave (MelWavePlan, lanes = 64) + log: per round every lane walks ONE
@@ -218,6 +254,7 @@ __device__ __forceinline__ void mel64_walk_log(const float *mag, float *lmf, int
 
 // DCT of the (up to) 4 frames whose log energies wait in lm[4][FS] (lm_fs4), rows out_row0 .. out_row0 + count - 1 of
 // feat: 64 columns per pass on the matrix pipe (dct_mfma4), or -- without a DCT -- the log energies themselves.
+template <int DEPTH>
 __device__ __forceinline__ void dct4_store(const float *lm, int FS, __amdgpu_buffer_rsrc_t rsrc, int table_bytes, int ks,
                                            int tiles64, bool has_dct, int lane, int cols, float *feat, int64_t feat_pitch,
                                            int64_t out_row0, int count)
@@ -226,7 +263,7 @@ __device__ __forceinline__ void dct4_store(const float *lm, int FS, __amdgpu_buf
         const float *arow = lm + (lane & 3) * FS;
         for (int tile = 0; tile < tiles64; ++tile) {
             float res[4];
-            dct_mfma4(arow, rsrc, table_bytes, lane, tile, ks, res);
+            dct_mfma4<DEPTH>(arow, rsrc, table_bytes, lane, tile, ks, res);
             const int col = 64 * tile + lane;
             if (col < cols) {
 #pragma unroll

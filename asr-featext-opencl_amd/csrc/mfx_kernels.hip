@@ -1433,7 +1433,7 @@ __global__ void __launch_bounds__(256) k_front_wave(FrontParams p)
                 group_sync();
                 if ((f & 3) == 3 || f == nf - 1) {
                     const int g0 = f & ~3;
-                    dct4_store(lm, FS, dct_rsrc, dct_bytes, dct_ks, dct_tiles64, p.dct_b4 != nullptr, lane, p.cols, p.feat,
+                    dct4_store<3>(lm, FS, dct_rsrc, dct_bytes, dct_ks, dct_tiles64, p.dct_b4 != nullptr, lane, p.cols, p.feat,
                                (int64_t)p.feat_pitch, ch.out_row + g0, f - g0 + 1);
                     group_sync();
                 }
@@ -1993,7 +1993,7 @@ __global__ void __launch_bounds__(256) k_melcep(MelcepParams p)
             mel64_walk_log(mag, lm + f * FS, FS - 1, s_mw, s_mst, s_mfid, s_L, rounds, RS, lane);
             wave_sync();
         }
-        dct4_store(lm, FS, dct_rsrc, dct_bytes, dct_ks, dct_tiles64, p.dct_b4 != nullptr, lane, p.cols, feat, (int64_t)p.feat_pitch,
+        dct4_store<3>(lm, FS, dct_rsrc, dct_bytes, dct_ks, dct_tiles64, p.dct_b4 != nullptr, lane, p.cols, feat, (int64_t)p.feat_pitch,
                    row0, count);
         wave_sync();
     }
