@@ -2104,6 +2104,92 @@ __global__ void __launch_bounds__(256) k_delta(DeltaParams p)
     }
 }
 
+// The same stage for wide rows whose column count is a multiple of 4 (BASELINE configs[4]: 40 columns, 120-float rows): a
+// work item is 4 consecutive columns, every load / LDS access / store a 16-byte word -- a quarter of k_delta's memory
+// instructions and no per-element index arithmetic.  Same arithmetic per element as k_delta (delta_quot), same tile shape;
+// requires cols % 4 == 0, src_pitch % 4 == 0, out_pitch == cols * groups, 16-byte aligned src / out.
+template <int ROWS>
+__global__ void __launch_bounds__(256) k_delta4(DeltaParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Segment sg = p.inline_seg ? p.seg0 : p.segs[blockIdx.y];
+    const int r0 = blockIdx.x * ROWS;
+    if (r0 >= sg.n_out) return;
+    const int rows = min(ROWS, sg.n_out - r0);
+    const int l1 = p.l1, l2 = p.l2, D = l1 + l2;
+    const int q = p.cols >> 2;                       // 16-byte words per group of columns
+    const int tid = threadIdx.x;
+    float4 *s_pad = (float4 *)smem;                  // [rows + 2 D][q]
+    float4 *s_d = s_pad + (ROWS + 2 * D) * q;        // [rows + 2 l2][q]
+    float4 *s_dd = s_d + (ROWS + 2 * l2) * q;        // [rows][q]
+    const uint32_t magic_q = 0xffffffffu / (uint32_t)q + 1; // floor(i / q) for i < 2^16
+    {
+        const int n_pad = (rows + 2 * D) * q;
+        for (int i = tid; i < n_pad; i += 256) {
+            const int rr = (int)__umulhi((uint32_t)i, magic_q), c = i - rr * q;
+            int sr = r0 + rr + sg.shift;
+            sr = max(sg.lo, min(sg.hi, sr));
+            s_pad[i] = ((const float4 *)(p.src + (sg.src_row0 + sr) * (int64_t)p.src_pitch))[c];
+        }
+    }
+    __syncthreads();
+    {
+        float den = 0.f;
+        for (int l = 1; l <= l1; ++l) den += (float)(l * l);
+        const float d1 = 2 * den, inv1 = 1.0f / d1;
+        const int n_d = (rows + 2 * l2) * q;
+        for (int i = tid; i < n_d; i += 256) {
+            float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int l = 1; l <= l1; ++l) {
+                const float4 a = s_pad[i + (l1 + l) * q], b = s_pad[i + (l1 - l) * q];
+                num.x = __builtin_fmaf((float)l, a.x - b.x, num.x);
+                num.y = __builtin_fmaf((float)l, a.y - b.y, num.y);
+                num.z = __builtin_fmaf((float)l, a.z - b.z, num.z);
+                num.w = __builtin_fmaf((float)l, a.w - b.w, num.w);
+            }
+            s_d[i] = make_float4(delta_quot(num.x, d1, inv1), delta_quot(num.y, d1, inv1), delta_quot(num.z, d1, inv1),
+                                 delta_quot(num.w, d1, inv1));
+        }
+    }
+    __syncthreads();
+    if (l2 > 0) {
+        float den2 = 0.f;
+        for (int l = 1; l <= l2; ++l) den2 += (float)(l * l);
+        const float d2 = 2 * den2, inv2 = 1.0f / d2;
+        const int n_dd = rows * q;
+        for (int i = tid; i < n_dd; i += 256) {
+            float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int l = 1; l <= l2; ++l) {
+                const float4 a = s_d[i + (l2 + l) * q], b = s_d[i + (l2 - l) * q];
+                num.x = __builtin_fmaf((float)l, a.x - b.x, num.x);
+                num.y = __builtin_fmaf((float)l, a.y - b.y, num.y);
+                num.z = __builtin_fmaf((float)l, a.z - b.z, num.z);
+                num.w = __builtin_fmaf((float)l, a.w - b.w, num.w);
+            }
+            s_dd[i] = make_float4(delta_quot(num.x, d2, inv2), delta_quot(num.y, d2, inv2), delta_quot(num.z, d2, inv2),
+                                  delta_quot(num.w, d2, inv2));
+        }
+        __syncthreads();
+    }
+    // the tile's output rows are one contiguous block: consecutive threads write consecutive 16-byte words, statics included
+    const int wq = q * (l2 > 0 ? 3 : 2);
+    const int stat_row = sg.static_off - sg.shift;
+    float4 *obase = (float4 *)(p.out + (sg.out_row0 + r0) * (int64_t)p.out_pitch);
+    const uint32_t magic_w = 0xffffffffu / (uint32_t)wq + 1;
+    const int n_o = rows * wq;
+    for (int i = tid; i < n_o; i += 256) {
+        const int rr = (int)__umulhi((uint32_t)i, magic_w), cc = i - rr * wq;
+        float4 v;
+        if (cc < q)
+            v = s_pad[(rr + stat_row) * q + cc];
+        else if (cc < 2 * q)
+            v = s_d[(rr + l2) * q + cc - q];
+        else
+            v = s_dd[rr * q + cc - 2 * q];
+        obase[i] = v;
+    }
+}
+
 // Delta stage from the compact statics (pitch 16) to whole output rows: the tile function of the fused
 // delta wave run by a block.  grid = (tiles, segments) as k_delta; requires cols <= 16, l1 > 0,
 // out_pitch == cols * (l2 > 0 ? 3 : 2), src_pitch == 16 and a 16-byte aligned `out`.
@@ -2556,6 +2642,9 @@ hipError_t launch_melcep(const MelcepParams &p, hipStream_t stream)
     return hipGetLastError();
 }
 
+#ifndef MFX_DELTA_WIDE_ROWS_V
+#define MFX_DELTA_WIDE_ROWS_V 32
+#endif
 hipError_t launch_delta(const DeltaParams &p, hipStream_t stream)
 {
     if (p.n_segs <= 0 || p.tiles_per_seg_max <= 0) return hipSuccess;
@@ -2576,6 +2665,22 @@ hipError_t launch_delta(const DeltaParams &p, hipStream_t stream)
                 hipLaunchKernelGGL((k_delta16<0, 0>), dim3(tiles_x, q.n_segs), dim3(256), lds16, stream, q);
         }
         return hipGetLastError();
+    }
+    // wide rows in whole 16-byte words: the vectorised form (C5: k_delta 0.052 ms -> see profiles/r03)
+    if (p.cols > 16 && (p.cols & 3) == 0 && p.l1 > 0 && (p.src_pitch & 3) == 0 && p.out_pitch == p.cols * groups &&
+        ((uintptr_t)p.out & 15) == 0 && ((uintptr_t)p.src & 15) == 0) {
+        constexpr int R4 = MFX_DELTA_WIDE_ROWS_V;
+        const size_t lds4 = (size_t)((R4 + 2 * D) + (R4 + 2 * p.l2) + R4) * p.cols * sizeof(float);
+        if (lds4 <= 64 * 1024) {
+            const int tiles_x4 = p.tiles_per_seg_max * (kDeltaRows / R4);
+            for (int s0 = 0; s0 < p.n_segs; s0 += 65535) {
+                DeltaParams qd = p;
+                qd.segs = p.segs + s0;
+                qd.n_segs = (p.n_segs - s0) < 65535 ? (p.n_segs - s0) : 65535;
+                hipLaunchKernelGGL((k_delta4<R4>), dim3(tiles_x4, qd.n_segs), dim3(256), lds4, stream, qd);
+            }
+            return hipGetLastError();
+        }
     }
     const bool fast16 = p.cols <= 16;
     const int cw = fast16 ? 16 : p.cols;
