@@ -1387,6 +1387,7 @@ _F2048 = [  # W, S, sr, nb, nc, c0, dyn, channels, alpha
     (1025, 512, 44100.0, 40, 13, False, 0, 2, 1.0),      # odd window length, few filters, one DCT tile
     (1100, 300, 32000.0, 200, 60, False, 2, 1, 1.07),    # 7 rounds of 32 filters, 4 DCT tiles; fewer waves per block (LDS)
     (1050, 350, 44100.0, 64, 0, False, 1, 2, 1.0),       # log mel energies as the features (no DCT)
+    (1102, 441, 44100.0, 100, 70, True, 0, 2, 1.0),      # 71 columns: two 64-column passes of the matrix-pipe DCT
 ]
 
 
