@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
     };
 
 #ifdef MFX_STAMPS
-    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_rt0;
+    unsigned long long st_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_rt0;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt0)::"memory");
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
@@ -263,6 +263,10 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
             const int f = f0 + half;
             const bool last = f0 + 2 >= n_live;
             MFX_STAMP2(0);
+#ifdef MFX_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (stamp builds only: the wait for the prefetched samples on its own)
+            MFX_STAMP2(12);
+#endif
             // ---- framing + window: z[n2] = (w[2n] x[2n], w[2n+1] x[2n+1]), n = l + 32 n2
             float2 z[32];
 #pragma unroll
@@ -355,6 +359,7 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
                     plane[M - l - 32 * k1] = __builtin_amdgcn_sqrtf(br * br + bi * bi); // |X[1024 - k]| / W2
                 }
             }
+            MFX_STAMP2(10);
             { // bin 512 pairs with itself: Z[512] is register 16 of lane 0 (S = 2 Re, T = cs[512] * 2i Im)
                 const float2 zk = z[16], w = *s_cs512;
                 const float sr = zk.x + zk.x, di = zk.y + zk.y;
@@ -368,6 +373,7 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
                 issue(cnxt, half);
             else
                 issue(ccur, f + 2);
+            MFX_STAMP2(11);
             wave_sync();
 
             MFX_STAMP2(5);
@@ -463,11 +469,11 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
     }
 #ifdef MFX_STAMPS
     if (lane == 0 && p.spec) {
-        unsigned long long *o = (unsigned long long *)p.spec + (size_t)(blockIdx.x * n_waves + wave) * 10;
+        unsigned long long *o = (unsigned long long *)p.spec + (size_t)(blockIdx.x * n_waves + wave) * 14;
         unsigned long long st_rt1;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1)::"memory");
         st_acc[9] = st_rt1 - st_rt0; // 100 MHz ticks over the same span
-        for (int i = 0; i < 10; ++i) o[i] = st_acc[i];
+        for (int i = 0; i < 14; ++i) o[i] = st_acc[i];
     }
 #endif
 }

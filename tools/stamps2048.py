@@ -18,10 +18,11 @@ for _ in range(3):
     m.batch_run_device(pcm.data_ptr(), n_utt * n, out.data_ptr())
 m.synchronize()
 NW = 256 * 12
-raw = m.debug_read(4)[:NW * 20].view(np.uint64).reshape(NW, 10).astype(np.float64)
-names = ["loop top", "load wait+cvt+window", "pass 1 + twiddle", "transposition", "pass 2", "split + magnitudes + prefetch issue",
-         "mel walk + log", "DCT + store", "chunk switch"]
-tot = raw[:, :9].sum(1)
+raw = m.debug_read(4)[:NW * 28].view(np.uint64).reshape(NW, 14).astype(np.float64)
+names = ["loop top", "convert + window", "pass 1 + twiddle", "transposition", "pass 2", "(after the prefetch issue: sync)",
+         "mel walk + log", "DCT + store", "chunk switch", None, "split: partner fetch + pairs + magnitude writes", "bin 512 + prefetch issue", "wait for the prefetched samples", None]
+idx = [0, 12, 1, 2, 3, 4, 10, 11, 5, 6, 7, 8]
+tot = raw[:, idx].sum(1)
 rt = raw[:, 9]
 ok = tot > 0
 print("shader clock over the wave's life: median %.3f GHz; wave life median %.1f us, max %.1f us" % (
@@ -31,6 +32,6 @@ print("wave life percentiles (us): min %.0f p5 %.0f p25 %.0f p50 %.0f p75 %.0f p
 iters = total / 2.0 / ok.sum()
 print("waves with data:", int(ok.sum()), " mean cycles per wave: %.0f  (%.1f iterations per wave -> %.0f cycles per iteration)" % (
     tot[ok].mean(), iters, tot[ok].mean() / iters))
-for i in range(9):
+for i in idx:
     print("%-38s %6.1f %%   %9.0f cycles/wave  %7.0f cycles/iteration" % (names[i], 100 * raw[:, i].sum() / tot.sum(), raw[:, i][ok].mean(),
                                                                           raw[:, i][ok].mean() / iters))
