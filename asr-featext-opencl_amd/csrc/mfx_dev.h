@@ -16,6 +16,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // All cross-lane traffic inside a wave goes through LDS instructions of that same wave, which the
 // LDS executes in issue order; only the compiler has to be kept from reordering around it.
+// (L + R) >> 1 of one stereo sample word (L | R << 16) as a float: the two sign-extended halves in ONE sub-word add
+// (left to itself the compiler builds the overflow-free average from xor / and / 16-bit shift / 16-bit add: five
+// operations per sample, each at the slow issue rate -- k_front2048 0.346 -> 0.332 ms on C5, profiles/r03/abx_c5_cvt_sdwa_add.txt)
+__device__ __forceinline__ float stereo_mean(uint32_t d)
+{
+    int s;
+    asm("v_add_u32_sdwa %0, sext(%1), sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+        : "=v"(s)
+        : "v"(d));
+    return (float)(s >> 1);
+}
+
 __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -278,8 +278,8 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
                 float x0, x1;
                 if (STEREO) { // one 32-bit word per sample (L | R << 16); mono = (L + R) >> 1 as the reference driver's caller
                     const uint32_t d0 = raw[2 * j], d1 = raw[2 * j + 1];
-                    x0 = (float)(((int)(short)(d0 & 0xffffu) + ((int)d0 >> 16)) >> 1);
-                    x1 = (float)(((int)(short)(d1 & 0xffffu) + ((int)d1 >> 16)) >> 1);
+                    x0 = stereo_mean(d0);
+                    x1 = stereo_mean(d1);
                 } else {
                     const uint32_t d = raw[j];
                     x0 = (float)(int)(short)(d & 0xffffu);

@@ -1718,8 +1718,8 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
                     const bool has1 = 2 * n + 1 < W;
                     if (ch_n == 2) {
                         const uint32_t d0 = has1 ? raw[2 * j] : raw[2 * j + 1], d1 = raw[2 * j + 1];
-                        x0 = (float)(((int)(short)(d0 & 0xffffu) + ((int)d0 >> 16)) >> 1);
-                        if (has1) x1 = (float)(((int)(short)(d1 & 0xffffu) + ((int)d1 >> 16)) >> 1);
+                        x0 = stereo_mean(d0);
+                        if (has1) x1 = stereo_mean(d1);
                     } else {
                         const uint32_t d = raw[2 * j];
                         x0 = (float)(int)(short)(has1 ? (d & 0xffffu) : (d >> 16));
@@ -1739,8 +1739,8 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
                         const uint32_t *w32 = (const uint32_t *)p.pcm + (s0 + 2 * n) - (has1 ? 0 : 1);
                         const Pair32 dd = *(const Pair32 *)w32;
                         const uint32_t d0 = has1 ? dd.x : dd.y, d1 = dd.y;
-                        x0 = (float)(((int)(short)(d0 & 0xffffu) + ((int)d0 >> 16)) >> 1);
-                        if (has1) x1 = (float)(((int)(short)(d1 & 0xffffu) + ((int)d1 >> 16)) >> 1);
+                        x0 = stereo_mean(d0);
+                        if (has1) x1 = stereo_mean(d1);
                     } else {
                         // mono at an odd sample offset: the pair as ONE 4-byte load at 2-byte alignment
                         const bool has1 = 2 * n + 1 < W;

@@ -24,6 +24,7 @@
 #include <atomic>
 #include <charconv>
 #include <future>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -524,30 +525,60 @@ void worker(const Options &o, int device, float sr, const std::vector<std::strin
 {
     try {
         const long W = (long)(sr * o.window_ms * 1e-3), S = (long)(sr * o.shift_ms * 1e-3);
-        MfccHip param(o.sample_limit, (int)W, (int)S, o.banks, sr, o.low, o.high, o.ceps, o.c0, o.lift,
-                      (Normalizer::norm_t)o.norm, (ParamBase::dyn_t)o.dyn, o.l1, o.l2, o.norm_after_dyn, device,
-                      o.bug_compat, o.batch_mb > 0 ? MFX_ENGINE_STREAM_KERNELS : 0);
-        if (g_time.on) g_time.t_created = now_ns();
+        // The extractor (HIP start-up, code object load, tables: 0.1-0.3 s of a fresh process) is created on a helper
+        // thread while this one claims and reads the first batch of files: reading needs nothing from the device.
+        auto make_param = [&] {
+            std::unique_ptr<MfccHip> p(new MfccHip(o.sample_limit, (int)W, (int)S, o.banks, sr, o.low, o.high, o.ceps, o.c0, o.lift,
+                                                  (Normalizer::norm_t)o.norm, (ParamBase::dyn_t)o.dyn, o.l1, o.l2,
+                                                  o.norm_after_dyn, device, o.bug_compat,
+                                                  o.batch_mb > 0 ? MFX_ENGINE_STREAM_KERNELS : 0));
+            std::vector<float> window((size_t)W);
+            for (long i = 0; i < W; ++i) // ASR_OCL.cpp:149-151
+                window[i] = (float)(0.56f - 0.46f * std::cos((2.0f * M_PI * i) / W)) / 32768.f;
+            p->set_window(window.data());
+            if (g_time.on) g_time.t_created = now_ns();
+            return p;
+        };
+        Batch slots[2]; // (declared before the extractor: their pinned buffers outlive nothing of it, and the first fills early)
+        std::future<bool> prep;
+        const int D = o.dyn == 0 ? 0 : o.dyn == 1 ? o.l1 : o.l1 + o.l2;
+        const long long cap = (long long)o.batch_mb * 1024 * 1024 / 2;
+        std::unique_ptr<MfccHip> param_owner;
+        if (o.batch_mb > 0) {
+            // largest block one set_input takes (parambase.cpp:12-13,16-19; the extractor reports the same number)
+            const int limit0 = (int)std::floor(float(o.sample_limit - (W - S)) / S) * (int)S + (int)(W - S);
+            std::future<std::unique_ptr<MfccHip>> created = std::async(std::launch::async, make_param);
+            prep = std::async(std::launch::async, [&, limit0] {
+                return prepare_batch(slots[0], o, files, next, sr, cap, limit0, (int)W, (int)S, D);
+            });
+            try {
+                param_owner = created.get();
+            } catch (...) {
+                prep.wait();
+                throw;
+            }
+            if (param_owner->get_input_buffer_size() != limit0) {
+                prep.wait();
+                throw std::runtime_error("input block size mismatch");
+            }
+        } else {
+            param_owner = make_param();
+        }
+        MfccHip &param = *param_owner;
         struct LoopEnd { // (runs before the extractor is destroyed: declared after it)
             ~LoopEnd()
             {
                 if (g_time.on) g_time.t_loop_end = now_ns();
             }
         } loop_end;
-        std::vector<float> window((size_t)W);
-        for (long i = 0; i < W; ++i) // ASR_OCL.cpp:149-151
-            window[i] = (float)(0.56f - 0.46f * std::cos((2.0f * M_PI * i) / W)) / 32768.f;
-        param.set_window(window.data());
         Scratch sc;
         if (o.batch_mb > 0) {
             // ---- batches of whole files: read batch k + 1 and write batch k - 1 (helper threads) beside the device calls
             // of batch k (this thread)
             const int limit = param.get_input_buffer_size(), width = param.get_output_data_width();
-            const int D = o.dyn == 0 ? 0 : o.dyn == 1 ? o.l1 : o.l1 + o.l2, cols = width / (1 + o.dyn);
-            const long long cap = (long long)o.batch_mb * 1024 * 1024 / 2;
+            const int cols = width / (1 + o.dyn);
             const long double dt = o.bug_compat ? (long double)(o.shift_ms / sr) : o.shift_ms / 1000.0L;
             const long double t0 = o.bug_compat ? (long double)(0.5f * o.window_ms / sr) : 0.5L * o.window_ms / 1000.0L;
-            Batch slots[2];
             std::vector<std::vector<char>> text_bufs((size_t)std::max(o.io_threads, 1));
             auto write_batch = [&](Batch *b) {
                 const long long tww = g_time.on ? now_ns() : 0;
@@ -590,9 +621,6 @@ void worker(const Options &o, int device, float sr, const std::vector<std::strin
                 if (g_time.on) g_time.write_wall += now_ns() - tww;
             };
             int cur = 0;
-            std::future<bool> prep = std::async(std::launch::async, [&, cur] {
-                return prepare_batch(slots[cur], o, files, next, sr, cap, limit, (int)W, (int)S, D);
-            });
             std::future<void> writer;
             for (;;) {
                 const long long tw0 = g_time.on ? now_ns() : 0;

@@ -13,4 +13,11 @@ for mode in "" "--htk"; do
     python3 -c "print('%-5s %-32s rc %d: %8.1f files/s' % ('$mode' or 'text', '$cfg', $rc, $N / ($e - $s)))"; tail -2 $D/err
   done
 done
+# the same over 8 x N files (short paths: the argument list stays under the kernel's limit): start-up amortised
+cp $R/tests/golden/a0001.wav $D/a.wav; args=""; M=$((8 * N))
+for i in $(seq 1 $M); do args="$args $D/a.wav $D/p$i"; done
+for mode in "" "--htk"; do
+  s=$(date +%s.%N); $EXE $OPT $mode --timing $args > /dev/null 2> $D/err; rc=$?; e=$(date +%s.%N)
+  python3 -c "print('%-5s %-32s rc %d: %8.1f files/s' % ('$mode' or 'text', '($M files)', $rc, $M / ($e - $s)))"; tail -2 $D/err
+done
 rm -rf $D
