@@ -9,6 +9,7 @@ namespace mfx {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers

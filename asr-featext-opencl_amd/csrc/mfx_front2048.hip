@@ -223,11 +223,13 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
         const int voff = (f * p.shift + 2 * l) * (STEREO ? 4 : 2);
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
+            // (the row's constant goes in as the scalar offset: added to the lane's offset by the address unit, no vector add)
             if (STEREO) {
-                raw[2 * j] = __builtin_amdgcn_raw_buffer_load_b32(x.rsrc, voff + 256 * j, 0, 0);
-                raw[2 * j + 1] = __builtin_amdgcn_raw_buffer_load_b32(x.rsrc, voff + 256 * j + 4, 0, 0);
+                const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(x.rsrc, voff, 256 * j, 0);
+                raw[2 * j] = d[0];
+                raw[2 * j + 1] = d[1];
             } else {
-                raw[j] = __builtin_amdgcn_raw_buffer_load_b32(x.rsrc, voff + 128 * j, 0, 0);
+                raw[j] = __builtin_amdgcn_raw_buffer_load_b32(x.rsrc, voff, 128 * j, 0);
             }
         }
     };
