@@ -323,9 +323,34 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=device)
+            # RCCL for the device-side barrier / reductions, gloo beside it: should RCCL fail to come up on some rank
+            # (no collective is on the data path -- it is only the stopwatch's barrier), all ranks agree over gloo to
+            # finish on CPU tensors, and the line says so (config.collective_backend)
+            import datetime
+            dist.init_process_group(backend="cpu:gloo,cuda:nccl", device_id=device, timeout=datetime.timedelta(seconds=300))
+            bad = 0
+            try:
+                probe = torch.ones(1, device=device)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    bad = 1
+            except Exception as e:   # noqa: BLE001 -- whatever RCCL raised, the benchmark itself does not need it
+                sys.stderr.write("bench.py rank %d: RCCL did not initialise (%s); falling back to gloo\n" % (rank, str(e)[:200]))
+                bad = 1
+            flag = torch.tensor([bad], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                backend = "gloo"
         else:
             dist.init_process_group(backend=backend)
+
+
+    def barrier():   # on the backend that came up (device tensor over RCCL, or CPU tensor over gloo)
+        t = torch.zeros(1, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        if backend == "nccl":
+            torch.cuda.synchronize()
 
     pkg = G.load_package()
     wl = WORKLOADS[args.workload]
@@ -385,7 +410,7 @@ def main():
     m.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
-        dist.barrier()
+        barrier()
     m.profile_enable(True)
     m.profile_read(reset=True)
     torch.cuda.synchronize()
@@ -396,7 +421,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        dist.barrier()
+        barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -480,6 +505,7 @@ def main():
                    "frames_per_step": frames_all, "frames_rank0_per_step": frames_rank, "utterances_rank0": n_utt_rank,
                    "utterances_total": wl["n_utt_total"] if strong else wl["n_utt"] * world,
                    "utterance_ids_rank0_head": [int(v) for v in utt_ids[:4]],
+                   "collective_backend": ("rccl" if backend == "nccl" else backend) if dist is not None else None,
                    "sharding": "round-robin utterance shards (rank r owns r, r + N, ...), no collective" if strong
                                else "independent utterance shards per rank, no collective",
                    "step_pipelining": "delta tail of step i overlaps front end of step i+1" if args.overlap else "off"},
@@ -506,11 +532,14 @@ def main():
             result["cpu_baseline"]["sample"] = "the stream cut into 10 s pieces: " + result["cpu_baseline"]["sample"]
         result["cpu_baseline"]["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
     m.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)   # (before the teardown: a hiccup there must not lose the line)
+    if dist is not None:
+        try:
+            barrier()
+            dist.destroy_process_group()
+        except Exception as e:   # noqa: BLE001
+            sys.stderr.write("bench.py rank %d: process-group teardown: %s\n" % (rank, str(e)[:200]))
 
 
 if __name__ == "__main__":

@@ -910,6 +910,25 @@ def test_bench_self_launch_two_ranks():
     assert abs(d["value"] - 2 * 8 * 98 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
 
 
+def test_bench_two_ranks_default_backend_or_agreed_fallback():
+    """The default collective backend of `bench.py --gpus N` is RCCL.  Two ranks pinned to ONE device: RCCL either comes
+    up or refuses the duplicate device -- in that case every rank must agree (over gloo) to finish the stopwatch's
+    barriers on CPU tensors, and the line must still be produced and say which backend carried them."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MFX_BENCH_BACKEND")}
+    env.update(MFX_BENCH_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--settle-ms", "5", "--workload", "T", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["collective_backend"] in ("rccl", "gloo")
+    assert abs(d["value"] - 2 * 8 * 98 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
 def test_bench_self_launch_two_ranks_strong_scaling():
     """`bench.py --gpus 2 --scaling strong`: ONE job (workload T: 13 utterances) sharded round-robin over the two ranks
     (7 + 6 utterances), total frames / max-over-ranks time, `scaling: "strong"`, and the CPU baseline on rank 0 at N > 1."""
