@@ -319,6 +319,7 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
+    group_dev = None   # the RCCL group (device tensors); None: the default gloo group carries the barriers
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
@@ -327,16 +328,18 @@ def main():
             # (no collective is on the data path -- it is only the stopwatch's barrier), all ranks agree over gloo to
             # finish on CPU tensors, and the line says so (config.collective_backend)
             import datetime
-            dist.init_process_group(backend="cpu:gloo,cuda:nccl", device_id=device, timeout=datetime.timedelta(seconds=300))
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
             bad = 0
             try:
+                group_dev = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300))
                 probe = torch.ones(1, device=device)
-                dist.all_reduce(probe)
+                dist.all_reduce(probe, group=group_dev)
                 torch.cuda.synchronize()
                 if int(probe.item()) != world:
                     bad = 1
             except Exception as e:   # noqa: BLE001 -- whatever RCCL raised, the benchmark itself does not need it
-                sys.stderr.write("bench.py rank %d: RCCL did not initialise (%s); falling back to gloo\n" % (rank, str(e)[:200]))
+                sys.stderr.write("bench.py rank %d: RCCL did not initialise (%s); falling back to gloo\n"
+                                 % (rank, " ".join(str(e).split())[:300]))
                 bad = 1
             flag = torch.tensor([bad], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
@@ -348,7 +351,7 @@ def main():
 
     def barrier():   # on the backend that came up (device tensor over RCCL, or CPU tensor over gloo)
         t = torch.zeros(1, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t)
+        dist.all_reduce(t, group=group_dev if backend == "nccl" else None)
         if backend == "nccl":
             torch.cuda.synchronize()
 
@@ -423,7 +426,7 @@ def main():
     if dist is not None:
         barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group_dev if backend == "nccl" else None)
         elapsed = float(t.item())
     launches, kernel_ms = m.profile_read(reset=True)
     m.profile_enable(False)
@@ -431,7 +434,7 @@ def main():
     frames_rank = int(total_rows)
     if dist is not None:   # strong scaling: the shards differ by one utterance at most, the total is the sum over ranks
         t = torch.tensor([frames_rank], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group_dev if backend == "nccl" else None)
         frames_all = int(t.item())
     else:
         frames_all = frames_rank
