@@ -375,6 +375,10 @@ int run_norm(mfx_handle *h, float *data, int pitch, int col0, const Segment *seg
         np.seg0 = *seg0;
         np.n_segs = 1;
     }
+    if (!use_last && !(h->cfg.engine & MFX_ENGINE_NORM_TWO_KERNELS) && norm_fused_fits(max_rows, h->cols)) {
+        HIP_TRY(h, launch_norm_fused(np, h->stream)); // short segments: one read of the rows, one launch
+        return MFX_OK;
+    }
     if (!use_last) HIP_TRY(h, launch_norm_stats(np, h->stream));
     HIP_TRY(h, launch_norm_apply(np, h->stream));
     return MFX_OK;

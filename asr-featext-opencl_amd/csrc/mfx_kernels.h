@@ -190,6 +190,9 @@ hipError_t launch_norm_stats(const NormParams &p, hipStream_t stream);
 // doubles of NormParams::partial for n_segs segments of at most max_rows rows (0: none needed)
 size_t norm_partial_doubles(int n_segs, int max_rows, int cols);
 hipError_t launch_norm_apply(const NormParams &p, hipStream_t stream);
+// statistics + apply in one launch, for segments of at most 48 KB of rows (norm_fused_fits); same bits as the pair above
+bool norm_fused_fits(int max_rows, int cols);
+hipError_t launch_norm_fused(const NormParams &p, hipStream_t stream);
 
 // dynamic LDS bytes one block of the 512-point kernel needs for these parameters
 size_t front512_lds_bytes(const FrontParams &p);

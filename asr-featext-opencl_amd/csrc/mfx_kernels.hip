@@ -2230,6 +2230,7 @@ __global__ void __launch_bounds__(256, 7) k_delta16(DeltaParams p)
 // computes them over the block it delivers and re-uses them for the flush rows (mfcccpu.cpp:377-388).
 // ------------------------------------------------------------------------------------------------
 constexpr int kNormChunkRows = 4096;
+constexpr size_t kNormSegLdsBytes = 54 * 1024; // k_norm_seg: dynamic LDS per block (1024 rows of 13 columns: a 10 s utterance; two blocks per CU)
 
 __device__ __forceinline__ void norm_finish(const NormParams &p, int seg, int c, int n, double S, double S2, float mn, float mx)
 {
@@ -2333,6 +2334,103 @@ __global__ void __launch_bounds__(256) k_norm_apply(NormParams p)
             *q = v - st[c];
         else
             *q = (v - st[c]) * st[cols + c];
+    }
+}
+
+// Statistics + apply of one SHORT segment in one block (an utterance of the batch entries, a small streaming block):
+// the segment's rows are read once into LDS, the statistics are formed exactly as k_norm_stats forms them (same thread
+// per (row class, column), same order of the double additions, same tree -- the results are the same bits), then every
+// row is normalised from LDS and written back.  One read and one write of the data instead of two reads and one write,
+// one launch instead of two: the reference's default configuration (CVN on 13 columns, ASR_OCL.cpp:560) spends
+// 0.051 ms per 998 000 frames in the two-kernel form.  p.chunks = rows the block's LDS holds (a longer segment is
+// processed from memory, correct but slow: the launcher does not choose this kernel for those).
+#ifndef MFX_NORM_SEG_THREADS
+#define MFX_NORM_SEG_THREADS 512
+#endif
+constexpr int kNormSegThreads = MFX_NORM_SEG_THREADS; // the statistics keep k_norm_stats' 256-thread mapping; all threads move the rows
+__global__ void __launch_bounds__(kNormSegThreads) k_norm_seg(NormParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_rows[];
+    __shared__ double s_sum[256], s_sum2[256];
+    __shared__ float s_min[256], s_max[256], s_st[512];
+    const Segment sg = p.inline_seg ? p.seg0 : p.segs[blockIdx.x];
+    const int cols = p.cols, n_out = sg.n_out;
+    const int n = sg.pad > 0 ? sg.pad : sg.n_out;
+    const int tid = threadIdx.x;
+    float *base = p.data + (sg.out_row0 + p.row_off) * (int64_t)p.pitch + p.col0;
+    const bool in_lds = n_out <= p.chunks;
+    const int total = n_out * cols;
+    const uint32_t magic = 0xffffffffu / (uint32_t)cols + 1; // i / cols for i < 2^32 / cols (LDS-sized products)
+    if (in_lds) { // 16 reads in flight per thread (a plain loop waits for every read before the next)
+        const bool contig = p.pitch == cols;
+        for (int i0 = tid; i0 < total; i0 += kNormSegThreads * 16) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = min(i0 + kNormSegThreads * k, total - 1); // (clamped, not predicated: no branch, all reads issued at once)
+                const int r = (int)__umulhi((uint32_t)i, magic), c = i - r * cols;
+                v[k] = base[contig ? (int64_t)i : (int64_t)r * p.pitch + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = i0 + kNormSegThreads * k;
+                if (i < total) s_rows[i] = v[k];
+            }
+        }
+        __syncthreads();
+    }
+    int lg = 0;
+    while ((1 << lg) < cols) ++lg;
+    const int Cp = 1 << lg, rpp = 256 >> lg;
+    const int rr = tid >> lg, c = tid & (Cp - 1);
+    double sum = 0, sum2 = 0;
+    float mn = 3.402823466e+38f, mx = -3.402823466e+38f;
+    if (c < cols && tid < 256)
+        for (int r = rr; r < n; r += rpp) {
+            const float v = in_lds ? s_rows[r * cols + c] : base[(int64_t)r * p.pitch + c];
+            sum += v;
+            sum2 += (double)(v * v);
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
+    if (tid < 256) {
+        s_sum[tid] = sum;
+        s_sum2[tid] = sum2;
+        s_min[tid] = mn;
+        s_max[tid] = mx;
+    }
+    __syncthreads();
+    for (int s = rpp >> 1; s > 0; s >>= 1) {
+        if (rr < s) { // (rr < s <= rpp / 2: threads of the first 256 only)
+            const int o = tid + (s << lg);
+            s_sum[tid] += s_sum[o];
+            s_sum2[tid] += s_sum2[o];
+            s_min[tid] = fminf(s_min[tid], s_min[o]);
+            s_max[tid] = fmaxf(s_max[tid], s_max[o]);
+        }
+        __syncthreads();
+    }
+    if (rr == 0 && c < cols) {
+        norm_finish(p, blockIdx.x, c, n, s_sum[tid], s_sum2[tid], s_min[tid], s_max[tid]);
+        const float *st = p.stats + (int64_t)blockIdx.x * 2 * cols; // (this thread's own writes)
+        s_st[c] = st[c];
+        s_st[256 + c] = st[cols + c];
+    }
+    __syncthreads();
+    if (in_lds) {
+        for (int i = tid; i < total; i += kNormSegThreads) {
+            const int r = (int)__umulhi((uint32_t)i, magic), cc = i - r * cols;
+            const float v = s_rows[i];
+            base[(int64_t)r * p.pitch + cc] = p.norm_type == 1 ? v - s_st[cc] : (v - s_st[cc]) * s_st[256 + cc];
+        }
+    } else {
+        for (int64_t i = tid; i < (int64_t)n_out * cols; i += kNormSegThreads) {
+            const int64_t r = i / cols;
+            const int cc = (int)(i - r * cols);
+            float *q = base + r * p.pitch + cc;
+            const float v = *q;
+            *q = p.norm_type == 1 ? v - s_st[cc] : (v - s_st[cc]) * s_st[256 + cc];
+        }
     }
 }
 
@@ -2727,6 +2825,28 @@ hipError_t launch_norm_stats(const NormParams &p, hipStream_t stream)
         if (chunks > 1) q.partial = p.partial + (int64_t)s0 * chunks * 4 * p.cols;
         hipLaunchKernelGGL(k_norm_stats, dim3(chunks, q.n_segs), dim3(256), 0, stream, q);
         if (chunks > 1) hipLaunchKernelGGL(k_norm_finalize, dim3(q.n_segs), dim3(256), 0, stream, q);
+    }
+    return hipGetLastError();
+}
+
+// stats + apply in one launch when every segment's rows fit one block's LDS (see k_norm_seg)
+bool norm_fused_fits(int max_rows, int cols)
+{
+    return max_rows > 0 && cols > 0 && cols <= 256 && (size_t)max_rows * cols * sizeof(float) <= kNormSegLdsBytes;
+}
+
+hipError_t launch_norm_fused(const NormParams &p, hipStream_t stream)
+{
+    if (p.n_segs <= 0) return hipSuccess;
+    if (!norm_fused_fits(p.max_rows, p.cols)) return hipErrorInvalidValue;
+    const size_t lds = (size_t)p.max_rows * p.cols * sizeof(float);
+    for (int s0 = 0; s0 < p.n_segs; s0 += 65535) {
+        NormParams q = p;
+        q.segs = p.segs + s0;
+        q.stats = p.stats + (int64_t)s0 * 2 * p.cols;
+        q.n_segs = (p.n_segs - s0) < 65535 ? (p.n_segs - s0) : 65535;
+        q.chunks = p.max_rows; // rows the block's LDS holds
+        hipLaunchKernelGGL(k_norm_seg, dim3(q.n_segs), dim3(kNormSegThreads), lds, stream, q);
     }
     return hipGetLastError();
 }

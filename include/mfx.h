@@ -97,6 +97,9 @@ typedef struct mfx_config {
 #define MFX_ENGINE_FUSE_DELTA 2   /* 512-point batch path: delta / delta-delta computed by a wave of the front-end kernel
                                      instead of the separate delta kernel (slower on MI355X)        */
 
+#define MFX_ENGINE_NORM_TWO_KERNELS 16 /* normaliser: statistics and apply as two launches also where one block's LDS holds a
+                                          segment's rows (the one-launch form computes the same bits)                    */
+
 typedef struct mfx_handle mfx_handle;
 
 /* ---- lifetime: replaces `new MfccOpenCL(..., cl_device_id)` (ASR_OCL.cpp:140-143,

@@ -889,6 +889,42 @@ def test_bench_two_rank_launch_path(tmp_path):
     assert 14000 <= rf["flops_per_frame"] <= 16000 and 9000 <= rf["staged_bytes_per_frame"] <= 9300
 
 
+@pytest.mark.parametrize("norm", [1, 2, 3])
+@pytest.mark.parametrize("dyn,nad", [(0, True), (2, True), (2, False)])
+def test_one_launch_normaliser_same_bits_as_two_kernels(pkg, orc, norm, dyn, nad):
+    """k_norm_seg (statistics + apply of a short segment in one block, rows through LDS) against k_norm_stats +
+    k_norm_apply (mfx_config.engine = MFX_ENGINE_NORM_TWO_KERNELS): the same bits, on the batch entry (ragged utterances,
+    one segment each) and on the streaming interface (blocks + flush, statistics re-used for the flush rows); the
+    two-kernel form is the one every normalisation parity test of rounds 1-2 ran against the oracle
+    (normalizercpu.cpp:22-89)."""
+    lens = [16000, 4321, 30011, 9000, 16000, 2400]
+    pcm = np.concatenate([synth_utterance(n, 40 + i) for i, n in enumerate(lens)])
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    kw = dict(norm=norm, dyn=dyn, nad=nad)
+    m1, _, _ = make_pair(pkg, orc, 40000, **kw)
+    m2, _, _ = make_pair(pkg, orc, 40000, engine=pkg.mfcc.ENGINE_NORM_TWO_KERNELS, **kw)
+    rows1, total1 = m1.batch_plan(offs, lens)
+    rows2, total2 = m2.batch_plan(offs, lens)
+    assert total1 == total2 and total1 > 0
+    a, b = m1.batch_run_host(pcm), m2.batch_run_host(pcm)
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+    for blk in (16000, 5000):
+        got = []
+        for m in (m1, m2):
+            out = []
+            for pos in range(0, 30011, blk):
+                n = m.set_input(pcm[pos:pos + blk][:max(0, 30011 - pos)])
+                if n > 0:
+                    m.apply()
+                    out.append(m.get_output_data(n))
+            n = m.flush()
+            if n > 0:
+                m.apply()
+                out.append(m.get_output_data(n))
+            got.append(np.concatenate(out))
+        assert got[0].shape == got[1].shape and np.array_equal(got[0], got[1])
+
+
 def test_bench_self_launch_two_ranks():
     """`python bench.py --gpus 2` with NO external launcher: the parent starts the two ranks itself (before it touches
     the GPU), relays rank 0's single JSON line and reports n_gpus == 2 (the reference's analogue is
