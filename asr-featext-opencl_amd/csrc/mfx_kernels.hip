@@ -2345,7 +2345,7 @@ __global__ void __launch_bounds__(256) k_norm_apply(NormParams p)
 // 0.051 ms per 998 000 frames in the two-kernel form.  p.chunks = rows the block's LDS holds (a longer segment is
 // processed from memory, correct but slow: the launcher does not choose this kernel for those).
 #ifndef MFX_NORM_SEG_THREADS
-#define MFX_NORM_SEG_THREADS 512
+#define MFX_NORM_SEG_THREADS 1024
 #endif
 constexpr int kNormSegThreads = MFX_NORM_SEG_THREADS; // the statistics keep k_norm_stats' 256-thread mapping; all threads move the rows
 __global__ void __launch_bounds__(kNormSegThreads) k_norm_seg(NormParams p)
