@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
                     const float *arow = lm + (lane & 3) * lmFS;
                     for (int tile = 0; tile < dct_tiles64; ++tile) {
                         float res[4];
-                        dct_mfma4<6>(arow, dct_rsrc, dct_bytes, lane, tile, dct_ks, res);
+                        dct_mfma4<7>(arow, dct_rsrc, dct_bytes, lane, tile, dct_ks, res);
                         const int col = 64 * tile + lane;
                         if (col < p.cols) {
 #pragma unroll
