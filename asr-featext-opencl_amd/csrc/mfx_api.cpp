@@ -50,6 +50,8 @@ struct DevBuf {
 
 } // namespace
 
+constexpr size_t kSmallBlock = (size_t)1 << 20; // below this a copy kernel replaces the DMA command (streaming interface)
+
 struct mfx_handle {
     mfx_config cfg{};
     int device = 0;
@@ -108,9 +110,14 @@ struct mfx_handle {
     bool block_applied = false;
     DevBuf<float> d_spec, d_src, d_blk, d_stats_stream;
     DevBuf<Chunk> d_chunks_stream;
+    int stream_chunk_frames = 16;
     int n_chunks_stream_max = 0;
     int16_t *h_stage = nullptr; // pinned
     size_t h_stage_n = 0;
+    // small-block handles (every block under 1 MB): the carried tail stays on the HOST, inside the pinned staging buffer, and
+    // goes up again in front of the next block -- one copy kernel per set_input instead of copy + device-to-device tail copy
+    bool host_tail = false;
+    size_t stage_tail_off = 0;  // samples: where the pending tail (h->remaining samples) starts in h_stage
     float *h_out_stage = nullptr;         // pinned staging of get_output_data (allocated on first use)
     size_t h_out_stage_n = 0;
     hipEvent_t ev_copy[16] = {};          // chunk events of the pipelined device-to-host copy
@@ -349,8 +356,9 @@ int prof_collect(mfx_handle *h)
 }
 
 // ---- normalisation helper: stats (unless reused) + apply over one column group
+// groups > 1: the column groups col0 + g * cols (g < groups) each with statistics at stats + g * group_stats_stride
 int run_norm(mfx_handle *h, float *data, int pitch, int col0, const Segment *segs, int n_segs, const Segment *seg0,
-             int row_off, float *stats, bool use_last, int max_rows)
+             int row_off, float *stats, bool use_last, int max_rows, int groups = 1, size_t group_stats_stride = 0)
 {
     NormParams np;
     std::memset(&np, 0, sizeof(np));
@@ -376,11 +384,17 @@ int run_norm(mfx_handle *h, float *data, int pitch, int col0, const Segment *seg
         np.n_segs = 1;
     }
     if (!use_last && !(h->cfg.engine & MFX_ENGINE_NORM_TWO_KERNELS) && norm_fused_fits(max_rows, h->cols)) {
-        HIP_TRY(h, launch_norm_fused(np, h->stream)); // short segments: one read of the rows, one launch
+        np.groups = groups;
+        np.group_stats_stride = (int64_t)group_stats_stride;
+        HIP_TRY(h, launch_norm_fused(np, h->stream)); // short segments: one read of the rows, ONE launch for all groups
         return MFX_OK;
     }
-    if (!use_last) HIP_TRY(h, launch_norm_stats(np, h->stream));
-    HIP_TRY(h, launch_norm_apply(np, h->stream));
+    for (int g = 0; g < groups; ++g) {
+        np.col0 = col0 + g * h->cols;
+        np.stats = stats + (size_t)g * group_stats_stride;
+        if (!use_last) HIP_TRY(h, launch_norm_stats(np, h->stream));
+        HIP_TRY(h, launch_norm_apply(np, h->stream));
+    }
     return MFX_OK;
 }
 
@@ -660,17 +674,23 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
     if (hipMemset(h->d_stats_stream.p, 0, (size_t)3 * 2 * h->cols * sizeof(float)) != hipSuccess)
         return bail(MFX_ERR_DEVICE);
     {
-        h->n_chunks_stream_max = (h->cap_rows + kChunkFrames - 1) / kChunkFrames;
+        // work items of a streaming block: 16 frames, or 4 where a whole block is only a few thousand frames (one 10-s
+        // utterance = 62 items of 16 frames would occupy 4 of 256 CUs, every wave running 4 iterations back to back)
+        h->stream_chunk_frames = h->cap_rows <= 16384 ? 4 : kChunkFrames;
+        const int cf = h->stream_chunk_frames;
+        h->n_chunks_stream_max = (h->cap_rows + cf - 1) / cf;
         std::vector<Chunk> ch(h->n_chunks_stream_max);
         for (int i = 0; i < h->n_chunks_stream_max; ++i) {
-            ch[i].pcm_off = (int64_t)i * kChunkFrames * h->S;
-            ch[i].out_row = (int64_t)i * kChunkFrames;
-            ch[i].n_frames = kChunkFrames;
+            ch[i].pcm_off = (int64_t)i * cf * h->S;
+            ch[i].out_row = (int64_t)i * cf;
+            ch[i].n_frames = cf;
             ch[i].pad = 0;
         }
         if (upload(h->d_chunks_stream, ch) != hipSuccess) return bail(MFX_ERR_DEVICE);
     }
-    h->h_stage_n = (size_t)h->input_buffer_size;
+    h->host_tail = !(h->cfg.engine & MFX_ENGINE_DMA_SMALL_BLOCKS) && (h->carry_capacity + 8) * sizeof(int16_t) < kSmallBlock;
+    // (+ 16 bytes: small blocks are staged at the destination's alignment; host_tail: tail + block, up to the carry capacity)
+    h->h_stage_n = (h->host_tail ? h->carry_capacity : (size_t)h->input_buffer_size) + 8;
     if (hipHostMalloc((void **)&h->h_stage, h->h_stage_n * sizeof(int16_t), hipHostMallocDefault) != hipSuccess)
         return bail(MFX_ERR_DEVICE);
 
@@ -866,6 +886,11 @@ bool is_pinned_host(const void *p)
 
 constexpr size_t kCopyChunk = (size_t)4 << 20;
 
+bool small_block(const mfx_handle *h, size_t bytes)
+{
+    return bytes > 0 && bytes < kSmallBlock && !(h->cfg.engine & MFX_ENGINE_DMA_SMALL_BLOCKS);
+}
+
 // host block -> device, asynchronous on the stream; `src` is free for the caller when this returns
 int upload_block(mfx_handle *h, int16_t *d_dst, const int16_t *src, size_t samples, bool *direct)
 {
@@ -875,6 +900,14 @@ int upload_block(mfx_handle *h, int16_t *d_dst, const int16_t *src, size_t sampl
         HIP_TRY(h, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, h->stream));
         if (!h->ev_copy[0]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_copy[0], hipEventDisableTiming));
         HIP_TRY(h, hipEventRecord(h->ev_copy[0], h->stream));
+        return MFX_OK;
+    }
+    if (small_block(h, bytes)) {
+        // a small block: into the pinned staging buffer at the destination's alignment, then a copy KERNEL reads it over the
+        // link (one launch; a DMA command of this size costs more in latency than in transfer)
+        char *stage = (char *)h->h_stage + ((uintptr_t)d_dst & 15);
+        std::memcpy(stage, src, bytes);
+        HIP_TRY(h, launch_copy_small(d_dst, stage, bytes, h->stream));
         return MFX_OK;
     }
     for (size_t off = 0; off < bytes; off += kCopyChunk) { // staging copy of chunk c+1 runs under the DMA of chunk c
@@ -889,6 +922,28 @@ int upload_block(mfx_handle *h, int16_t *d_dst, const int16_t *src, size_t sampl
 int download_rows(mfx_handle *h, float *dst, const float *d_src, size_t count)
 {
     const size_t bytes = count * sizeof(float);
+    if (small_block(h, bytes)) {
+        // small: a copy kernel writes the rows into page-locked memory (the caller's buffer if it is pinned, else the
+        // staging buffer at the source's alignment), one stream wait, one memcpy
+        if (is_pinned_host(dst)) {
+            HIP_TRY(h, launch_copy_small(dst, d_src, bytes, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            return MFX_OK;
+        }
+        if (h->h_out_stage_n < count + 4) {
+            if (h->h_out_stage) (void)hipHostFree(h->h_out_stage);
+            h->h_out_stage = nullptr;
+            h->h_out_stage_n = 0;
+            const size_t want = std::max(count, (size_t)h->cap_rows * h->width) + 4;
+            HIP_TRY(h, hipHostMalloc((void **)&h->h_out_stage, want * sizeof(float), hipHostMallocDefault));
+            h->h_out_stage_n = want;
+        }
+        char *stage = (char *)h->h_out_stage + ((uintptr_t)d_src & 15);
+        HIP_TRY(h, launch_copy_small(stage, d_src, bytes, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        std::memcpy(dst, stage, bytes);
+        return MFX_OK;
+    }
     if (bytes < kCopyChunk || is_pinned_host(dst)) {
         HIP_TRY(h, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -928,7 +983,7 @@ int stream_front(mfx_handle *h, int wcnd)
     p.pcm = h->d_carry[h->cur].p;
     p.pcm_total = (int64_t)h->d_carry[h->cur].n;
     p.chunks = h->d_chunks_stream.p;
-    p.n_chunks = (wcnd + kChunkFrames - 1) / kChunkFrames;
+    p.n_chunks = (wcnd + h->stream_chunk_frames - 1) / h->stream_chunk_frames;
     p.row_limit = wcnd;
     p.channels = 1;
     p.pair_ok = ((h->S % 2) == 0 && (h->W % 2) == 0) ? 1 : 0; // carry-buffer frames start at multiples of S
@@ -947,9 +1002,14 @@ int stream_front(mfx_handle *h, int wcnd)
 int carry_tail(mfx_handle *h, int total_samples)
 {
     const int other = h->cur ^ 1;
-    if (h->remaining > 0)
-        HIP_TRY(h, hipMemcpyAsync(h->d_carry[other].p, h->d_carry[h->cur].p + (total_samples - h->remaining),
-                                  sizeof(int16_t) * (size_t)h->remaining, hipMemcpyDeviceToDevice, h->stream));
+    if (h->remaining > 0) {
+        const size_t bytes = sizeof(int16_t) * (size_t)h->remaining;
+        const int16_t *src = h->d_carry[h->cur].p + (total_samples - h->remaining);
+        if (small_block(h, bytes))
+            HIP_TRY(h, launch_copy_small(h->d_carry[other].p, src, bytes, h->stream));
+        else
+            HIP_TRY(h, hipMemcpyAsync(h->d_carry[other].p, src, bytes, hipMemcpyDeviceToDevice, h->stream));
+    }
     h->cur = other;
     return MFX_OK;
 }
@@ -987,7 +1047,10 @@ extern "C" int mfx_set_input(mfx_handle *h, const int16_t *pcm, int32_t samples,
     h->last_calc_flushed = h->flushed;
     int window_count = 0, wcnd = 0;
     if (h->last_calc_flushed) {
-        {
+        if (h->host_tail) {
+            std::memcpy(h->h_stage, pcm, (size_t)samples * sizeof(int16_t));
+            HIP_TRY(h, launch_copy_small(h->d_carry[h->cur].p, h->h_stage, (size_t)samples * sizeof(int16_t), h->stream));
+        } else {
             int rcu = upload_block(h, h->d_carry[h->cur].p, pcm, (size_t)samples, &direct);
             if (rcu != MFX_OK) return rcu;
         }
@@ -999,13 +1062,26 @@ extern "C" int mfx_set_input(mfx_handle *h, const int16_t *pcm, int32_t samples,
         int rc = stream_front(h, wcnd);
         if (rc != MFX_OK) return rc;
         h->remaining = samples - processed + W - S;
-        rc = carry_tail(h, samples);
-        if (rc != MFX_OK) return rc;
+        if (h->host_tail) {
+            h->stage_tail_off = (size_t)(samples - h->remaining);
+        } else {
+            rc = carry_tail(h, samples);
+            if (rc != MFX_OK) return rc;
+        }
         h->flushed = false;
         h->samples = samples;
     } else {
         if ((size_t)samples + (size_t)h->remaining > h->carry_capacity) return fail(h, MFX_ERR_BUFFER_TOO_SMALL, kMsgBuffer);
-        {
+        if (h->host_tail) {
+            // the pending tail moves to the front of the staging buffer (the stream is idle: no kernel is reading it), the
+            // block goes behind it, and ONE copy kernel takes both to the front of the carry buffer
+            if (h->stage_tail_off > 0 && h->remaining > 0)
+                std::memmove(h->h_stage, h->h_stage + h->stage_tail_off, (size_t)h->remaining * sizeof(int16_t));
+            h->stage_tail_off = 0;
+            std::memcpy(h->h_stage + h->remaining, pcm, (size_t)samples * sizeof(int16_t));
+            HIP_TRY(h, launch_copy_small(h->d_carry[h->cur].p, h->h_stage,
+                                         ((size_t)h->remaining + (size_t)samples) * sizeof(int16_t), h->stream));
+        } else {
             int rcu = upload_block(h, h->d_carry[h->cur].p + h->remaining, pcm, (size_t)samples, &direct);
             if (rcu != MFX_OK) return rcu;
         }
@@ -1019,8 +1095,12 @@ extern "C" int mfx_set_input(mfx_handle *h, const int16_t *pcm, int32_t samples,
             window_count = 0;
         const int processed = window_count * S + W - S;
         h->remaining = total - processed + W - S;
-        int rc = carry_tail(h, total);
-        if (rc != MFX_OK) return rc;
+        if (h->host_tail) {
+            h->stage_tail_off = (size_t)(total - h->remaining);
+        } else {
+            int rc = carry_tail(h, total);
+            if (rc != MFX_OK) return rc;
+        }
         h->samples = total;
     }
     h->block_frames = window_count;
@@ -1043,6 +1123,13 @@ extern "C" int mfx_flush(mfx_handle *h, int32_t *frames_out)
     const int wcnd = estimated_window_count_f32(h->remaining, h->W, h->S);
     const int window_count = wcnd - h->D;
     if (window_count <= 0) return MFX_OK;
+    if (h->host_tail && h->remaining > 0) { // the tail is on the host: up it goes, to the front of the carry buffer
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->stage_tail_off > 0)
+            std::memmove(h->h_stage, h->h_stage + h->stage_tail_off, (size_t)h->remaining * sizeof(int16_t));
+        h->stage_tail_off = 0;
+        HIP_TRY(h, launch_copy_small(h->d_carry[h->cur].p, h->h_stage, (size_t)h->remaining * sizeof(int16_t), h->stream));
+    }
     int rc = stream_front(h, wcnd);
     if (rc != MFX_OK) return rc;
     h->block_frames = window_count;
@@ -1248,11 +1335,9 @@ int apply_impl(mfx_handle *h, const float *alphas, int n_alpha)
 
     if (norm && h->cfg.norm_after_dyn) {
         const int groups = h->width / h->cols;
-        for (int g = 0; g < groups; ++g) {
-            rc = run_norm(h, d_blk, h->width, g * h->cols, segs_out, n_tab, sweep ? nullptr : &sd, 0,
-                          d_stats + (size_t)g * n_tab * 2 * h->cols, use_last, wc);
-            if (rc != MFX_OK) return rc;
-        }
+        rc = run_norm(h, d_blk, h->width, 0, segs_out, n_tab, sweep ? nullptr : &sd, 0, d_stats, use_last, wc, groups,
+                      (size_t)n_tab * 2 * h->cols);
+        if (rc != MFX_OK) return rc;
     }
     h->block_applied = true;
     h->sweep_n = sweep ? n_alpha : 0;
@@ -1735,11 +1820,9 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
     }
     if (norm && h->cfg.norm_after_dyn) {
         const int groups = h->width / h->cols;
-        for (int g = 0; g < groups; ++g) {
-            rc = run_norm(h, d_out, h->width, g * h->cols, h->d_segs.p + u0, u1 - u0, nullptr, 0,
-                          h->d_stats_batch.p + ((size_t)g * h->n_utt + u0) * 2 * h->cols, false, h->tiles_max * 64);
-            if (rc != MFX_OK) return rc;
-        }
+        rc = run_norm(h, d_out, h->width, 0, h->d_segs.p + u0, u1 - u0, nullptr, 0, h->d_stats_batch.p + (size_t)u0 * 2 * h->cols,
+                      false, h->tiles_max * 64, groups, (size_t)h->n_utt * 2 * h->cols);
+        if (rc != MFX_OK) return rc;
     }
     if (split_tail) {
         HIP_TRY(h, hipEventRecord(h->ev_tail[sb], tail_stream));

@@ -174,6 +174,8 @@ struct NormParams {
     int32_t max_rows;      // largest row count of any segment (sizes the grids)
     int32_t chunks;        // set by the launcher: row chunks per segment
     double *partial;       // [n_segs][chunks][4][cols] scratch, needed when max_rows > 4096 (norm_partial_doubles)
+    int32_t groups;        // launch_norm_fused only: column groups col0 + g * cols normalised in ONE launch (0 / 1: one)
+    int64_t group_stats_stride; // floats between the statistics of consecutive groups
 };
 
 // All launchers are asynchronous on `stream` and return the launch status.
@@ -190,6 +192,8 @@ hipError_t launch_norm_stats(const NormParams &p, hipStream_t stream);
 // doubles of NormParams::partial for n_segs segments of at most max_rows rows (0: none needed)
 size_t norm_partial_doubles(int n_segs, int max_rows, int cols);
 hipError_t launch_norm_apply(const NormParams &p, hipStream_t stream);
+// copy of a small block (even byte count) by a kernel; either side may be page-locked host memory
+hipError_t launch_copy_small(void *dst, const void *src, size_t bytes, hipStream_t stream);
 // statistics + apply in one launch, for segments of at most 48 KB of rows (norm_fused_fits); same bits as the pair above
 bool norm_fused_fits(int max_rows, int cols);
 hipError_t launch_norm_fused(const NormParams &p, hipStream_t stream);

@@ -2232,17 +2232,22 @@ __global__ void __launch_bounds__(256, 7) k_delta16(DeltaParams p)
 constexpr int kNormChunkRows = 4096;
 constexpr size_t kNormSegLdsBytes = 54 * 1024; // k_norm_seg: dynamic LDS per block (1024 rows of 13 columns: a 10 s utterance; two blocks per CU)
 
-__device__ __forceinline__ void norm_finish(const NormParams &p, int seg, int c, int n, double S, double S2, float mn, float mx)
+__device__ __forceinline__ void norm_finish_to(float *st, int cols, int norm_type, int c, int n, double S, double S2, float mn,
+                                               float mx)
 {
     const float mean = (float)(S / n);
     float mult = 1.f;
-    if (p.norm_type == 2)
+    if (norm_type == 2)
         mult = (float)sqrt((n - 1) / (S2 - S * (S / n)));
-    else if (p.norm_type == 3)
+    else if (norm_type == 3)
         mult = 1.f / fmaxf(fabsf(mn - mean), fabsf(mx - mean));
-    float *st = p.stats + (int64_t)seg * 2 * p.cols;
     st[c] = mean;
-    st[p.cols + c] = mult;
+    st[cols + c] = mult;
+}
+
+__device__ __forceinline__ void norm_finish(const NormParams &p, int seg, int c, int n, double S, double S2, float mn, float mx)
+{
+    norm_finish_to(p.stats + (int64_t)seg * 2 * p.cols, p.cols, p.norm_type, c, n, S, S2, mn, mx);
 }
 
 __global__ void __launch_bounds__(256) k_norm_stats(NormParams p)
@@ -2357,7 +2362,9 @@ __global__ void __launch_bounds__(kNormSegThreads) k_norm_seg(NormParams p)
     const int cols = p.cols, n_out = sg.n_out;
     const int n = sg.pad > 0 ? sg.pad : sg.n_out;
     const int tid = threadIdx.x;
-    float *base = p.data + (sg.out_row0 + p.row_off) * (int64_t)p.pitch + p.col0;
+    // blockIdx.y = column group (static | delta | delta-delta blocks of the row, each with its own statistics)
+    float *base = p.data + (sg.out_row0 + p.row_off) * (int64_t)p.pitch + p.col0 + blockIdx.y * cols;
+    float *stats = p.stats + (int64_t)blockIdx.y * p.group_stats_stride + (int64_t)blockIdx.x * 2 * cols;
     const bool in_lds = n_out <= p.chunks;
     const int total = n_out * cols;
     const uint32_t magic = 0xffffffffu / (uint32_t)cols + 1; // i / cols for i < 2^32 / cols (LDS-sized products)
@@ -2411,10 +2418,9 @@ __global__ void __launch_bounds__(kNormSegThreads) k_norm_seg(NormParams p)
         __syncthreads();
     }
     if (rr == 0 && c < cols) {
-        norm_finish(p, blockIdx.x, c, n, s_sum[tid], s_sum2[tid], s_min[tid], s_max[tid]);
-        const float *st = p.stats + (int64_t)blockIdx.x * 2 * cols; // (this thread's own writes)
-        s_st[c] = st[c];
-        s_st[256 + c] = st[cols + c];
+        norm_finish_to(stats, cols, p.norm_type, c, n, s_sum[tid], s_sum2[tid], s_min[tid], s_max[tid]);
+        s_st[c] = stats[c]; // (this thread's own writes)
+        s_st[256 + c] = stats[cols + c];
     }
     __syncthreads();
     if (in_lds) {
@@ -2431,6 +2437,27 @@ __global__ void __launch_bounds__(kNormSegThreads) k_norm_seg(NormParams p)
             const float v = *q;
             *q = p.norm_type == 1 ? v - s_st[cc] : (v - s_st[cc]) * s_st[256 + cc];
         }
+    }
+}
+
+// Copy of a small block by a kernel instead of a DMA command (streaming interface, blocks under 1 MB: an SDMA copy of a few
+// hundred KB costs more in command latency than in transfer time).  Either side may be page-locked host memory (mapped into
+// the device's address space).  vec: dst and src are congruent modulo 16 -- 16-byte words between a head and a tail of
+// 2-byte units; else 2-byte units throughout (byte counts are even: int16 samples or float rows).
+__global__ void __launch_bounds__(256) k_copy_small(char *dst, const char *src, size_t bytes, int vec)
+{
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    if (vec) {
+        size_t head = (16 - ((uintptr_t)dst & 15)) & 15;
+        if (head > bytes) head = bytes;
+        const size_t nvec = (bytes - head) >> 4, tail0 = head + (nvec << 4);
+        const uint4 *s4 = (const uint4 *)(src + head);
+        uint4 *d4 = (uint4 *)(dst + head);
+        for (size_t v = gid; v < nvec; v += stride) d4[v] = s4[v];
+        if (gid < (head >> 1)) ((short *)dst)[gid] = ((const short *)src)[gid];
+        if (gid < ((bytes - tail0) >> 1)) ((short *)(dst + tail0))[gid] = ((const short *)(src + tail0))[gid];
+    } else {
+        for (size_t i = gid; i < (bytes >> 1); i += stride) ((short *)dst)[i] = ((const short *)src)[i];
     }
 }
 
@@ -2500,9 +2527,10 @@ hipError_t launch512(const FrontParams &p_in, hipStream_t stream)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    int blocks = (p.n_chunks + kWaves - 1) / kWaves;
+    // one block per CU; with fewer work items than that, one item per block (spread over the CUs: a small streaming
+    // block is latency, not throughput)
     const int cap = num_cus() * (32 / kWaves) / 2; // 16 waves per CU
-    if (blocks > cap) blocks = cap;
+    int blocks = p.n_chunks < cap ? p.n_chunks : cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((k_front512<A, S, NM, false>), dim3(blocks), dim3(kThreads), lds, stream, p);
     return hipGetLastError();
@@ -2846,8 +2874,21 @@ hipError_t launch_norm_fused(const NormParams &p, hipStream_t stream)
         q.stats = p.stats + (int64_t)s0 * 2 * p.cols;
         q.n_segs = (p.n_segs - s0) < 65535 ? (p.n_segs - s0) : 65535;
         q.chunks = p.max_rows; // rows the block's LDS holds
-        hipLaunchKernelGGL(k_norm_seg, dim3(q.n_segs), dim3(kNormSegThreads), lds, stream, q);
+        hipLaunchKernelGGL(k_norm_seg, dim3(q.n_segs, p.groups > 1 ? p.groups : 1), dim3(kNormSegThreads), lds, stream, q);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_small(void *dst, const void *src, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0) return hipSuccess;
+    if (bytes & 1) return hipErrorInvalidValue;
+    const int vec = (((uintptr_t)dst ^ (uintptr_t)src) & 15) == 0 ? 1 : 0;
+    const size_t items = vec ? (bytes >> 4) + 16 : (bytes >> 1);
+    size_t blocks = (items + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_copy_small, dim3((unsigned)blocks), dim3(256), 0, stream, (char *)dst, (const char *)src, bytes, vec);
     return hipGetLastError();
 }
 

@@ -207,7 +207,8 @@ def reference_window(window_size):
     return (inner.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
 
 
-ENGINE_NO_FRONT1024, ENGINE_FUSE_DELTA, ENGINE_NO_FRONT2048, ENGINE_STREAM_KERNELS, ENGINE_NORM_TWO_KERNELS = 1, 2, 4, 8, 16     # mfx_config.engine bits (include/mfx.h)
+ENGINE_NO_FRONT1024, ENGINE_FUSE_DELTA, ENGINE_NO_FRONT2048, ENGINE_STREAM_KERNELS, ENGINE_NORM_TWO_KERNELS = 1, 2, 4, 8, 16
+ENGINE_DMA_SMALL_BLOCKS = 32     # mfx_config.engine bits (include/mfx.h)
 
 
 class MfccHip:

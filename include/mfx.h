@@ -99,6 +99,8 @@ typedef struct mfx_config {
 
 #define MFX_ENGINE_NORM_TWO_KERNELS 16 /* normaliser: statistics and apply as two launches also where one block's LDS holds a
                                           segment's rows (the one-launch form computes the same bits)                    */
+#define MFX_ENGINE_DMA_SMALL_BLOCKS 32  /* streaming interface: blocks under 1 MB are copied by DMA commands (as larger ones are)
+                                           instead of by a copy kernel through the pinned staging buffers                 */
 
 typedef struct mfx_handle mfx_handle;
 

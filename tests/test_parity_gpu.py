@@ -925,6 +925,74 @@ def test_one_launch_normaliser_same_bits_as_two_kernels(pkg, orc, norm, dyn, nad
         assert got[0].shape == got[1].shape and np.array_equal(got[0], got[1])
 
 
+@pytest.mark.parametrize("norm,dyn", [(0, 2), (2, 2), (0, 0)])
+def test_small_block_copy_kernels_same_bits_as_dma(pkg, orc, norm, dyn):
+    """Streaming interface, blocks under 1 MB: the block goes to the device, the carried tail to the other carry buffer and
+    the rows back to the host through a copy KERNEL (pinned staging at the device address's alignment) instead of DMA
+    commands (mfx_config.engine = MFX_ENGINE_DMA_SMALL_BLOCKS keeps those).  Odd block lengths put the appended block and
+    the tail at every 2-byte alignment; the rows must be the same bits either way, from pageable and from pinned caller
+    buffers, and equal to the oracle's."""
+    import torch
+    pcm = synth_utterance(61003, 77)
+    kw = dict(norm=norm, dyn=dyn)
+    m1, cfg, w = make_pair(pkg, orc, 20000, **kw)
+    m2, _, _ = make_pair(pkg, orc, 20000, engine=pkg.mfcc.ENGINE_DMA_SMALL_BLOCKS, **kw)
+    blocks = [7001, 9999, 4443, 12345, 8000, 11111, 8104]
+    assert sum(blocks) == pcm.size
+
+    def run(m, pinned):
+        out, pos = [], 0
+        for b in blocks:
+            blk = pcm[pos:pos + b]
+            if pinned:
+                t = torch.empty(b, dtype=torch.int16).pin_memory()
+                t.numpy()[:] = blk
+                blk = t.numpy()
+            n = m.set_input(blk)
+            pos += b
+            if n > 0:
+                m.apply()
+                out.append(m.get_output_data(n))
+        n = m.flush()
+        if n > 0:
+            m.apply()
+            out.append(m.get_output_data(n))
+        return np.concatenate(out)
+
+    a, b = run(m1, False), run(m2, False)
+    assert a.shape == b.shape and np.isfinite(a).all() and np.array_equal(a, b)
+    assert np.array_equal(run(m1, True), a)
+    # rows straight into a PINNED caller buffer (the copy kernel writes it; deliberately at an odd float offset)
+    import ctypes as C
+    width = m1.get_output_data_width()
+    t_out = torch.empty(200 * width + 3, dtype=torch.float32).pin_memory()
+    got, pos = [], 0
+    for bl in blocks + [0]:
+        n = m1.set_input(pcm[pos:pos + bl]) if bl else m1.flush()
+        pos += bl
+        if n > 0:
+            m1.apply()
+            t_out.zero_()
+            rc = m1._L.mfx_get_output_data(m1._h, C.cast(t_out.data_ptr() + 12, C.POINTER(C.c_float)), n)
+            assert rc == 0
+            got.append(t_out.numpy()[3:3 + n * width].reshape(n, width).copy())
+    assert np.array_equal(np.concatenate(got), a)
+    if norm == 0:
+        o = orc.OracleMfcc(cfg, w)
+        rows, pos = [], 0
+        for bl in blocks:
+            n = o.set_input(pcm[pos:pos + bl])
+            pos += bl
+            if n > 0:
+                o.apply()
+                rows.append(o.get_output_data(n))
+        n = o.flush()
+        if n > 0:
+            o.apply()
+            rows.append(o.get_output_data(n))
+        assert_close(a, np.concatenate(rows), "small blocks through the copy kernels", groups=1 + dyn)
+
+
 def test_bench_self_launch_two_ranks():
     """`python bench.py --gpus 2` with NO external launcher: the parent starts the two ranks itself (before it touches
     the GPU), relays rank 0's single JSON line and reports n_gpus == 2 (the reference's analogue is
