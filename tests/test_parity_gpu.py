@@ -993,6 +993,44 @@ def test_small_block_copy_kernels_same_bits_as_dma(pkg, orc, norm, dyn):
         assert_close(a, np.concatenate(rows), "small blocks through the copy kernels", groups=1 + dyn)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_streaming_random_block_lengths_vs_oracle(pkg, orc, seed):
+    """Random block lengths from 1 sample to the whole input buffer (blocks that add no frame, odd lengths, full blocks),
+    delta context on and off, on a small-block handle (carried tail on the host, copy kernels) and on a large-block one
+    (device-side tail): block by block the same row counts as the oracle and rows within the parity bar
+    (segmentercpu.cpp:56-106 state machine, mfcccpu.cpp:371-444)."""
+    rng = np.random.default_rng(seed)
+    for ibs, dyn in ((20000, 2), (20000, 0), (700000, 2)):
+        pcm = synth_utterance(int(3.2 * ibs) + int(rng.integers(0, 999)), 100 + seed)
+        m, cfg, w = make_pair(pkg, orc, ibs, dyn=dyn)
+        o = orc.OracleMfcc(cfg, w)
+        lim = m.get_input_buffer_size()
+        pos, first, k = 0, True, 0
+        got, want = [], []
+        while pos < pcm.size:
+            hi = min(lim, pcm.size - pos)
+            b = hi if first else int(rng.choice([1, 7, 159, 160, 161, 401, int(rng.integers(1, hi + 1)), hi]))
+            b = max(1, min(b, hi))
+            first = False
+            n, no = m.set_input(pcm[pos:pos + b]), o.set_input(pcm[pos:pos + b])
+            assert n == no, "block %d (%d samples at %d): %d rows, oracle %d" % (k, b, pos, n, no)
+            pos += b
+            k += 1
+            if n > 0:
+                m.apply()
+                o.apply()
+                got.append(m.get_output_data(n))
+                want.append(o.get_output_data(n))
+        n, no = m.flush(), o.flush()
+        assert n == no
+        if n > 0:
+            m.apply()
+            o.apply()
+            got.append(m.get_output_data(n))
+            want.append(o.get_output_data(n))
+        assert_close(np.concatenate(got), np.concatenate(want), "random blocks ibs %d dyn %d" % (ibs, dyn), groups=1 + dyn)
+
+
 def test_bench_self_launch_two_ranks():
     """`python bench.py --gpus 2` with NO external launcher: the parent starts the two ranks itself (before it touches
     the GPU), relays rank 0's single JSON line and reports n_gpus == 2 (the reference's analogue is
