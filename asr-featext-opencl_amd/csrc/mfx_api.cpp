@@ -90,6 +90,8 @@ struct mfx_handle {
     DevBuf<float> d_mel64_w, d_dct_b;
     DevBuf<int32_t> d_mel64_start, d_mel64_fid;
     DevBuf<float> d_dct_b4;                          // k_front2048: DCT operands as 16-byte words
+    DevBuf<float> d_dct_b4s;                         // k_front2048: the split form for <= 40 columns (or empty)
+    int dct_split = 0;
     DevBuf<float> d_mel32_w;                         // k_front2048: the 32-lane plan
     DevBuf<int32_t> d_mel32_start, d_mel32_fid;
     MelWavePlan wplan32;
@@ -248,6 +250,17 @@ int refresh_mel(mfx_handle *h)
         std::vector<int32_t> L(h->wplan.L, h->wplan.L + 8);
         HIP_TRY(h, upload(h->d_mel64_L, L));
     }
+    {   // apply() runs k_melcep for every configuration: its tables + one wave's buffers must fit the CU's LDS (a few
+        // very wide filters on a long transform -- 8 filters over 1025 bins -- do not): refuse here, not at the first apply()
+        MelcepParams probe;
+        std::memset(&probe, 0, sizeof(probe));
+        probe.num_banks = h->nb;
+        probe.mel64_rounds = h->wplan.rounds;
+        probe.mel64_row_stride = h->wplan.row_stride;
+        probe.mag_floats = std::max(h->W2, (h->spec_pitch + 3) & ~3);
+        if (melcep_lds_bytes(probe, 1) > 160 * 1024)
+            return fail(h, MFX_ERR_CONFIG, "mel filterbank does not fit the kernels' LDS (very wide filters on a long transform)");
+    }
     h->wplan_ok = true;
     h->wplan32_ok = false;
     if (h->fast2048) { // k_front2048 walks the filters on the 32 lanes of each of a wave's two frames
@@ -312,6 +325,8 @@ void fill_front(const mfx_handle *h, FrontParams &p)
     for (int i = 0; i < 8; ++i) p.mel32_L[i] = h->wplan32.L[i];
     p.dct_b = h->ceps > 0 ? h->d_dct_b.p : nullptr;
     p.dct_b4 = h->ceps > 0 ? h->d_dct_b4.p : nullptr;
+    p.dct_b4s = (h->ceps > 0 && h->dct_split) ? h->d_dct_b4s.p : nullptr;
+    p.dct_split = h->ceps > 0 ? h->dct_split : 0;
     p.dct_tiles = h->dct_tiles;
     p.dct_ksteps = h->dct_ksteps;
     p.dct_stride = h->dct_stride;
@@ -455,6 +470,7 @@ extern "C" void mfx_destroy(mfx_handle *h)
     h->d_dct_b.release();
     h->d_mel32_w.release();
     h->d_dct_b4.release();
+    h->d_dct_b4s.release();
     h->d_mel32_start.release();
     h->d_mel32_fid.release();
     h->d_dct_t.release();
@@ -641,6 +657,11 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
                 if (upload(h->d_dct_b, ob) != hipSuccess) return bail(MFX_ERR_DEVICE);
                 build_dct_mfma_operands4(m, h->nb, h->dl, ob); // the 4x4x1 form: k_front2048, k_front_wave, k_melcep
                 if (upload(h->d_dct_b4, ob) != hipSuccess) return bail(MFX_ERR_DEVICE);
+                h->dct_split = (h->cfg.engine & MFX_ENGINE_NO_DCT_SPLIT) ? 0 : dct_split_mode(h->nb, h->dl);
+                if (h->dct_split) {
+                    build_dct_mfma_operands4_split(m, h->nb, h->dl, ob);
+                    if (upload(h->d_dct_b4s, ob) != hipSuccess) return bail(MFX_ERR_DEVICE);
+                }
             }
             if (h->fast512) {
                 std::vector<float> mt;

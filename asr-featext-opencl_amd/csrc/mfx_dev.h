@@ -231,6 +231,21 @@ __device__ __forceinline__ void dct_mfma4(const float *arow, __amdgpu_buffer_rsr
         dct_mfma4_impl<0, DEPTH>(arow, rsrc, table_bytes, lane, tile, ks, res);
 }
 
+// The split form of k_front2048 (build_dct_mfma_operands4_split): `group0` = first 1 KB K-group of the pass in the table,
+// `ks` K-groups of 4 bands; C5's 128 bands (16 / 4 groups) get the unrolled form.
+template <int DEPTH>
+__device__ __forceinline__ void dct_mfma4s(const float *arow, __amdgpu_buffer_rsrc_t rsrc, int table_bytes, int lane, int group0,
+                                           int ks, float (&res)[4])
+{
+    // (dct_mfma4_impl addresses K-group tile * ks + j4: with ks a divisor of group0 the pass starts at tile = group0 / ks)
+    if (ks == 16 && group0 == 0)
+        dct_mfma4_impl<16, DEPTH>(arow, rsrc, table_bytes, lane, 0, 16, res);
+    else if (ks == 4 && group0 == 16)
+        dct_mfma4_impl<4, DEPTH>(arow, rsrc, table_bytes, lane, 4, 4, res);
+    else
+        dct_mfma4_impl<0, DEPTH>(arow, rsrc, table_bytes, lane, group0 / ks, ks, res);
+}
+
 // One frame's mel filterbank on the 64 lanes of a wave (MelWavePlan, lanes = 64) + log: per round every lane walks ONE
 // filter's bins in ascending order, one chain of multiply-adds (mfcccpu.cpp:206-217); weights from the lane's own
 // zero-padded row (16-byte reads, disjoint bank quads), magnitudes as 8-byte reads from even starts the host spread over

@@ -118,7 +118,9 @@ __host__ __device__ inline size_t front2048_table_floats(int rounds, int row_str
            + (size_t)64 * rounds;             // starts + filter ids
 }
 
-template <bool STEREO>
+// SPLIT: the DCT in its split form (p.dct_split != 0: <= 40 columns, bands a multiple of 32) -- a build of its own, so that
+// neither form carries the other's code and scalar registers
+template <bool STEREO, bool SPLIT>
 __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(FrontParams p)
 {
     constexpr int M = 1024, NR = kRows2048;
@@ -253,8 +255,13 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
     }
     // the DCT's B operands [tiles][ksteps][64] through a buffer descriptor (offsets past the table return 0)
     const int dct_ks = p.dct_ksteps, dct_tiles64 = (p.dct_len + 63) >> 6; // bands / 4; groups of 64 output columns
-    const int dct_bytes = p.dct_b4 ? dct_tiles64 * dct_ks * 1024 : 0;
-    const __amdgpu_buffer_rsrc_t dct_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.dct_b4, 0, dct_bytes, 0x00020000);
+    // (the split form: nb / 8 K-groups of pass A, then nb / 32 of pass B, 1 KB each; ONE descriptor for whichever table this
+    // launch uses -- a second one costs scalar registers the kernel does not have)
+    const int dct_bytes = SPLIT      ? ((p.num_banks >> 3) + (p.dct_split > 1 ? (p.num_banks >> 5) : 0)) * 1024
+                          : p.dct_b4 ? dct_tiles64 * dct_ks * 1024
+                                     : 0;
+    const __amdgpu_buffer_rsrc_t dct_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(SPLIT ? p.dct_b4s : p.dct_b4), 0, dct_bytes, 0x00020000);
     int c_cur = draw(), c_nxt = draw();
     ChunkCtx ccur = make_ctx(c_cur), cnxt = make_ctx(c_nxt);
     issue(ccur, half);
@@ -441,7 +448,41 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
             if ((f0 & 2) || last) {
 #endif
                 const int g0 = f0 & ~3, gcount = (n_live - g0) < 4 ? (n_live - g0) : 4;
-                if (p.dct_b4) {
+                if (SPLIT) {
+                    // <= 40 columns, bands a multiple of 32 (build_dct_mfma_operands4_split): the 16 blocks of an instruction
+                    // are (column group, band part) pairs instead of 16 column groups of which 6 - 8 would be empty.
+                    // Pass A: lane = (band half kb = lane >> 5, column lane & 31); one instruction adds one band of EACH half.
+                    const int nbk = p.num_banks;
+                    float ra[4];
+                    dct_mfma4s<7>(lm + (lane & 3) * lmFS + (lane >> 5) * (nbk >> 1), dct_rsrc, dct_bytes, lane, 0, nbk >> 3, ra);
+                    // the halves meet: after the swap lanes 0..31 hold (frame 0 | frame 2), lanes 32..63 (frame 1 | frame 3)
+                    const auto a01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ra[0]), __float_as_uint(ra[1]), false, false);
+                    const auto a23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ra[2]), __float_as_uint(ra[3]), false, false);
+                    const float oA0 = __uint_as_float(a01[0]) + __uint_as_float(a01[1]);
+                    const float oA1 = __uint_as_float(a23[0]) + __uint_as_float(a23[1]);
+                    {
+                        const int col = lane & 31, fa = lane >> 5;
+                        if (col < p.cols) {
+                            if (fa < gcount) (p.feat + (out_row + g0 + fa) * (int64_t)p.feat_pitch)[col] = oA0;
+                            if (fa + 2 < gcount) (p.feat + (out_row + g0 + fa + 2) * (int64_t)p.feat_pitch)[col] = oA1;
+                        }
+                    }
+                    if (p.dct_split > 1) {
+                        // Pass B: lane = (band eighth kb = lane >> 3, column 32 + (lane & 7))
+                        float rb[4];
+                        dct_mfma4s<4>(lm + (lane & 3) * lmFS + (lane >> 3) * (nbk >> 3), dct_rsrc, dct_bytes, lane, nbk >> 3, nbk >> 5, rb);
+                        const auto b01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(rb[0]), __float_as_uint(rb[1]), false, false);
+                        const auto b23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(rb[2]), __float_as_uint(rb[3]), false, false);
+                        const float s01 = __uint_as_float(b01[0]) + __uint_as_float(b01[1]); // rows 0,1: frame 0; rows 2,3: frame 1
+                        const float s23 = __uint_as_float(b23[0]) + __uint_as_float(b23[1]); // rows 0,1: frame 2; rows 2,3: frame 3
+                        const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
+                        // 16-lane rows now hold frames 0, 2, 1, 3; lanes l and l + 8 of a row the last two band parts
+                        const float t = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+                        const float oB = t + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xf, 0xf, true)); // row_ror:8
+                        const int col = 32 + (lane & 7), row = lane >> 4, fb = ((row & 1) << 1) | (row >> 1);
+                        if (!(lane & 8) && col < p.cols && fb < gcount) (p.feat + (out_row + g0 + fb) * (int64_t)p.feat_pitch)[col] = oB;
+                    }
+                } else if (p.dct_b4) {
                     const float *arow = lm + (lane & 3) * lmFS;
                     for (int tile = 0; tile < dct_tiles64; ++tile) {
                         float res[4];
@@ -519,7 +560,9 @@ hipError_t launch_front2048(const FrontParams &p, int num_cus, hipStream_t strea
     const int nw = waves_2048(p);
     if (nw == 0) return hipErrorInvalidValue;
     const size_t lds = lds_bytes_2048(p, nw);
-    const void *fn = stereo ? (const void *)k_front2048<true> : (const void *)k_front2048<false>;
+    const bool split = p.dct_split != 0 && p.dct_b4s != nullptr;
+    const void *fn = stereo ? (split ? (const void *)k_front2048<true, true> : (const void *)k_front2048<true, false>)
+                            : (split ? (const void *)k_front2048<false, true> : (const void *)k_front2048<false, false>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -527,10 +570,14 @@ hipError_t launch_front2048(const FrontParams &p, int num_cus, hipStream_t strea
     int blocks = (p.n_chunks + nw - 1) / nw;
     if (blocks > num_cus) blocks = num_cus; // one block of up to 12 waves per CU
     if (blocks < 1) blocks = 1;
-    if (stereo)
-        hipLaunchKernelGGL((k_front2048<true>), dim3(blocks), dim3(nw * 64), lds, stream, p);
+    if (stereo && split)
+        hipLaunchKernelGGL((k_front2048<true, true>), dim3(blocks), dim3(nw * 64), lds, stream, p);
+    else if (stereo)
+        hipLaunchKernelGGL((k_front2048<true, false>), dim3(blocks), dim3(nw * 64), lds, stream, p);
+    else if (split)
+        hipLaunchKernelGGL((k_front2048<false, true>), dim3(blocks), dim3(nw * 64), lds, stream, p);
     else
-        hipLaunchKernelGGL((k_front2048<false>), dim3(blocks), dim3(nw * 64), lds, stream, p);
+        hipLaunchKernelGGL((k_front2048<false, false>), dim3(blocks), dim3(nw * 64), lds, stream, p);
     return hipGetLastError();
 }
 

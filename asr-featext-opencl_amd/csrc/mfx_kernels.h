@@ -97,6 +97,8 @@ struct FrontParams {
     // DCT on the matrix pipe: B operands [dct_tiles][dct_ksteps][64] (build_dct_mfma_operands), read from L1 / L2
     const float *dct_b;
     const float *dct_b4;          // 4x4x1 form: [ceil(dct_len / 64)][dct_ksteps][64][4] (k_front2048, build_dct_mfma_operands4)
+    const float *dct_b4s;         // k_front2048: the split form (build_dct_mfma_operands4_split) or nullptr
+    int32_t dct_split;            // dct_split_mode(): 0 none, 1 pass A (<= 32 columns), 2 passes A + B (<= 40 columns)
     int32_t dct_tiles, dct_ksteps;
     int32_t num_banks;
     int32_t dct_len;
@@ -188,6 +190,8 @@ hipError_t launch_front_generic(const FrontParams &p, bool fused, hipStream_t st
 size_t front_wave_lds_bytes(const FrontParams &p, bool fused);
 hipError_t launch_melcep(const MelcepParams &p, hipStream_t stream);
 hipError_t launch_delta(const DeltaParams &p, hipStream_t stream);
+// LDS of k_melcep with n_waves waves per block (the launcher takes as many of 4 as fit)
+size_t melcep_lds_bytes(const MelcepParams &p, int n_waves);
 hipError_t launch_norm_stats(const NormParams &p, hipStream_t stream);
 // doubles of NormParams::partial for n_segs segments of at most max_rows rows (0: none needed)
 size_t norm_partial_doubles(int n_segs, int max_rows, int cols);

@@ -259,6 +259,33 @@ void build_dct_mfma_operands4(const std::vector<float> &dct, int num_banks, int 
                 }
 }
 
+int dct_split_mode(int num_banks, int dct_len)
+{
+    if (num_banks % 32 != 0 || num_banks > 256 || dct_len < 1) return 0;
+    return dct_len <= 32 ? 1 : dct_len <= 40 ? 2 : 0;
+}
+
+void build_dct_mfma_operands4_split(const std::vector<float> &dct, int num_banks, int dct_len, std::vector<float> &out)
+{
+    const int mode = dct_split_mode(num_banks, dct_len);
+    out.clear();
+    if (mode == 0) return;
+    const int H = num_banks / 2, E = num_banks / 8, ga = H / 4, gb = mode == 2 ? E / 4 : 0;
+    out.assign((size_t)(ga + gb) * 64 * 4, 0.0f);
+    for (int g = 0; g < ga; ++g)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int u = 0; u < 4; ++u) {
+                const int m = (lane >> 5) * H + 4 * g + u, c = lane & 31;
+                if (c < dct_len) out[((size_t)g * 64 + lane) * 4 + u] = dct[(size_t)m * dct_len + c];
+            }
+    for (int g = 0; g < gb; ++g)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int u = 0; u < 4; ++u) {
+                const int m = (lane >> 3) * E + 4 * g + u, c = 32 + (lane & 7);
+                if (c < dct_len) out[((size_t)(ga + g) * 64 + lane) * 4 + u] = dct[(size_t)m * dct_len + c];
+            }
+}
+
 void build_dct_transposed(const std::vector<float> &dct, int num_banks, int dct_len, int &stride, int &nb_pad,
                           std::vector<float> &out)
 {

@@ -87,6 +87,16 @@ void build_dct_mfma_operands(const std::vector<float> &dct, int num_banks, int d
 // out[((tile * ks + j4) * 64 + lane) * 4 + u] = dct[4 j4 + u][64 tile + lane], ks = ceil(num_banks / 4), zero beyond the matrix.
 void build_dct_mfma_operands4(const std::vector<float> &dct, int num_banks, int dct_len, std::vector<float> &out);
 
+// k_front2048 with at most 40 output columns and a multiple of 32 bands: the 64-column tile of the 4x4x1 form would be
+// 37 - 50 % empty.  The 16 blocks of an instruction are dealt to (column group, band part) instead: pass A = 8 groups of 4
+// columns x 2 band halves (columns 0..31), pass B = 2 groups x 8 band eighths (columns 32..39); the parts are summed across
+// the wave afterwards.  mode 0: not applicable, 1: pass A alone (dct_len <= 32), 2: A + B.
+//   out = [nb / 8 groups of pass A][64][4] then [nb / 32 groups of pass B][64][4]:
+//   A: out[(g * 64 + lane) * 4 + u] = dct[(lane >> 5) * nb / 2 + 4 g + u][lane & 31]
+//   B: out[((nb / 8 + g) * 64 + lane) * 4 + u] = dct[(lane >> 3) * nb / 8 + 4 g + u][32 + (lane & 7)]
+int dct_split_mode(int num_banks, int dct_len);
+void build_dct_mfma_operands4_split(const std::vector<float> &dct, int num_banks, int dct_len, std::vector<float> &out);
+
 // Transposed, padded DCT matrix for the 512-point kernel: [cols][stride], stride / 4 odd,
 // row c = column c of the [num_banks][dct_len] matrix followed by zeros.
 void build_dct_transposed(const std::vector<float> &dct, int num_banks, int dct_len, int &stride, int &nb_pad,

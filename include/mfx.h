@@ -101,6 +101,8 @@ typedef struct mfx_config {
                                           segment's rows (the one-launch form computes the same bits)                    */
 #define MFX_ENGINE_DMA_SMALL_BLOCKS 32  /* streaming interface: blocks under 1 MB are copied by DMA commands (as larger ones are)
                                            instead of by a copy kernel through the pinned staging buffers                 */
+#define MFX_ENGINE_NO_DCT_SPLIT 64      /* 2048-point fused kernel: the DCT as one 64-column tile also where at most 40 columns
+                                           are wanted (else: column groups x band parts, summed across the wave)          */
 
 typedef struct mfx_handle mfx_handle;
 

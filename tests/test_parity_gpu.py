@@ -1549,6 +1549,10 @@ _F2048 = [  # W, S, sr, nb, nc, c0, dyn, channels, alpha
     (1100, 300, 32000.0, 200, 60, False, 2, 1, 1.07),    # 7 rounds of 32 filters, 4 DCT tiles; fewer waves per block (LDS)
     (1050, 350, 44100.0, 64, 0, False, 1, 2, 1.0),       # log mel energies as the features (no DCT)
     (1102, 441, 44100.0, 100, 70, True, 0, 2, 1.0),      # 71 columns: two 64-column passes of the matrix-pipe DCT
+    (1102, 441, 44100.0, 128, 25, True, 2, 2, 1.0),      # split DCT, pass A alone: 26 columns on 2 band halves
+    (1102, 440, 44100.0, 64, 39, True, 1, 1, 0.9),       # split DCT A + B at 64 bands (8 / 2 K-groups: the runtime-loop form), mono
+    (1100, 320, 32000.0, 256, 33, False, 0, 2, 1.0),     # split DCT A + B at 256 bands, 33 columns: one column in pass B
+    (1102, 441, 44100.0, 96, 32, False, 2, 2, 1.1),      # split DCT, pass A alone, exactly 32 columns, 96 bands
 ]
 
 
@@ -1609,6 +1613,12 @@ def test_front2048_configurations(pkg, orc, W, S, sr, nb, nc, c0, dyn, ch, alpha
         want = orc.run_utterance(cfg, mono[o_:o_ + n], w, alpha=alpha, bug_compat=False)
         assert want.shape[0] == T
         assert_close(got[rows[i]:rows[i] + T], want, "utterance %d (%d frames)" % (i, T), groups=g)
+    # the same batch with the DCT as one 64-column tile (mfx_config.engine = MFX_ENGINE_NO_DCT_SPLIT): float32 rounding apart
+    m3, _, _ = make_pair(pkg, orc, max(lens) + 2000, engine=pkg.mfcc.ENGINE_NO_DCT_SPLIT, **kw)
+    if alpha != 1.0:
+        m3.set_alpha(alpha)
+    m3.batch_plan(offs, lens)
+    assert_close(got, m3.batch_run_host(pcm), "k_front2048 split DCT vs one tile", groups=g)
 
 
 def test_c5_full_size_properties(pkg, orc):
