@@ -271,6 +271,7 @@ int refresh_mel(mfx_handle *h)
             FrontParams probe;
             std::memset(&probe, 0, sizeof(probe));
             probe.num_banks = h->nb;
+            probe.window_size = h->W; // (18 or 20 rows of window taps in LDS)
             probe.dct_ksteps = h->ceps > 0 ? (h->nb + 3) / 4 : 0;
             probe.mel32_rounds = h->wplan32.rounds;
             probe.mel32_row_stride = h->wplan32.row_stride;
@@ -1711,7 +1712,7 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
     const bool fused1024 = allow_fused && h->fast1024 && h->fused_ok && (h->W <= 512 || h->batch_aligned); // (long windows: aligned frames only)
     // (up to 2048 points the fused form saves the spectrum's round trip through HBM -- 8 KB per frame at 2048
     // points; at 4096 points the tables + per-wave buffers no longer leave enough waves per CU)
-    // (2048 points, window <= 1152 samples: two frames per wave; mono needs aligned sample pairs)
+    // (2048 points, window <= 1280 samples: two frames per wave; mono needs aligned sample pairs)
     const bool fused2048 = allow_fused && h->fast2048 && h->wplan32_ok && (h->channels == 2 || p.pair_ok);
     const bool fusedgen = allow_fused && !fused512 && !fused1024 && !fused2048 && h->W2 <= 2048 && h->wplan_ok &&
                           front_wave_lds_bytes(p, true) <= 160 * 1024;

@@ -58,7 +58,9 @@ namespace {
 #endif
 constexpr int kW2048 = MFX_W2048;        // waves per block; one block per CU (LDS: ~33 KB of tables + 10.5 KB per wave)
 constexpr int kPlane = 1040;      // floats per frame plane: 1024 transposition words / 1025 magnitudes + finite slack
-constexpr int kRows2048 = 18;     // rows of 32 sample pairs that can carry window taps: W <= 1152
+constexpr int kRows2048 = 18;     // rows of 32 sample pairs that can carry window taps: W <= 1152 (25 ms at 44.1 kHz)
+constexpr int kRows2048L = 20;    // the long-window build: W <= 1280 (25 ms at 48 kHz = 1200 taps)
+__host__ __device__ inline int rows2048(int window_size) { return window_size <= 64 * kRows2048 ? kRows2048 : kRows2048L; }
 
 // cos / sin of 2 pi e / 32
 __host__ __device__ constexpr float c32(int e)
@@ -109,9 +111,9 @@ __device__ __forceinline__ void fft32(float2 (&x)[32])
 }
 
 // LDS floats: shared tables, then per wave two planes and the log mel energies of 4 frames
-__host__ __device__ inline size_t front2048_table_floats(int rounds, int row_stride)
+__host__ __device__ inline size_t front2048_table_floats(int rounds, int row_stride, int rows)
 {
-    return 2 * (size_t)(32 * kRows2048)      // window pairs
+    return 2 * (size_t)(32 * rows)           // window pairs
            + 4 * (size_t)(16 * 32)            // pass twiddles, two per 16-byte word
            + 4 * (size_t)(8 * 32) + 4         // split twiddles, two per 16-byte word; + the self-paired bin 512
            + (size_t)32 * row_stride          // mel weight rows
@@ -120,10 +122,11 @@ __host__ __device__ inline size_t front2048_table_floats(int rounds, int row_str
 
 // SPLIT: the DCT in its split form (p.dct_split != 0: <= 40 columns, bands a multiple of 32) -- a build of its own, so that
 // neither form carries the other's code and scalar registers
-template <bool STEREO, bool SPLIT>
+// NR: rows of 32 sample pairs that carry window taps (18: W <= 1152; 20: W <= 1280) -- the zero rows fold away at compile time
+template <bool STEREO, bool SPLIT, int NR>
 __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(FrontParams p)
 {
-    constexpr int M = 1024, NR = kRows2048;
+    constexpr int M = 1024;
     constexpr int NWORD = STEREO ? 2 * NR : NR; // raw 32-bit words per lane and frame
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
@@ -454,7 +457,7 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
                     // Pass A: lane = (band half kb = lane >> 5, column lane & 31); one instruction adds one band of EACH half.
                     const int nbk = p.num_banks;
                     float ra[4];
-                    dct_mfma4s<7>(lm + (lane & 3) * lmFS + (lane >> 5) * (nbk >> 1), dct_rsrc, dct_bytes, lane, 0, nbk >> 3, ra);
+                    dct_mfma4s<(STEREO && NR > kRows2048) ? 5 : 7>(lm + (lane & 3) * lmFS + (lane >> 5) * (nbk >> 1), dct_rsrc, dct_bytes, lane, 0, nbk >> 3, ra);
                     // the halves meet: after the swap lanes 0..31 hold (frame 0 | frame 2), lanes 32..63 (frame 1 | frame 3)
                     const auto a01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ra[0]), __float_as_uint(ra[1]), false, false);
                     const auto a23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ra[2]), __float_as_uint(ra[3]), false, false);
@@ -525,7 +528,7 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
 
 bool front2048_supported(int fft_size, int window_size, int num_banks, int cols, int channels)
 {
-    return fft_size == 2048 && window_size > 0 && window_size <= 64 * kRows2048 && (channels == 1 || channels == 2) &&
+    return fft_size == 2048 && window_size > 0 && window_size <= 64 * kRows2048L && (channels == 1 || channels == 2) &&
            num_banks >= 1 && num_banks <= 256 && cols >= 1;
 }
 
@@ -533,7 +536,7 @@ namespace {
 int lm_fs(const FrontParams &p) { return lm_fs4(p.num_banks); }
 size_t lds_bytes_2048(const FrontParams &p, int n_waves)
 {
-    const size_t f = front2048_table_floats(p.mel32_rounds, p.mel32_row_stride) +
+    const size_t f = front2048_table_floats(p.mel32_rounds, p.mel32_row_stride, rows2048(p.window_size)) +
                      (size_t)n_waves * (2 * kPlane + 4 * (size_t)lm_fs(p)) + 4;
     return f * sizeof(float);
 }
@@ -561,23 +564,27 @@ hipError_t launch_front2048(const FrontParams &p, int num_cus, hipStream_t strea
     if (nw == 0) return hipErrorInvalidValue;
     const size_t lds = lds_bytes_2048(p, nw);
     const bool split = p.dct_split != 0 && p.dct_b4s != nullptr;
-    const void *fn = stereo ? (split ? (const void *)k_front2048<true, true> : (const void *)k_front2048<true, false>)
-                            : (split ? (const void *)k_front2048<false, true> : (const void *)k_front2048<false, false>);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    const bool wide = rows2048(p.window_size) == kRows2048L;
     int blocks = (p.n_chunks + nw - 1) / nw;
     if (blocks > num_cus) blocks = num_cus; // one block of up to 12 waves per CU
     if (blocks < 1) blocks = 1;
-    if (stereo && split)
-        hipLaunchKernelGGL((k_front2048<true, true>), dim3(blocks), dim3(nw * 64), lds, stream, p);
-    else if (stereo)
-        hipLaunchKernelGGL((k_front2048<true, false>), dim3(blocks), dim3(nw * 64), lds, stream, p);
-    else if (split)
-        hipLaunchKernelGGL((k_front2048<false, true>), dim3(blocks), dim3(nw * 64), lds, stream, p);
-    else
-        hipLaunchKernelGGL((k_front2048<false, false>), dim3(blocks), dim3(nw * 64), lds, stream, p);
+    hipError_t err = hipSuccess;
+    auto go = [&](auto kern) {
+        if (lds > 64 * 1024) err = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess) hipLaunchKernelGGL(kern, dim3(blocks), dim3(nw * 64), lds, stream, p);
+    };
+    if (wide) {
+        if (stereo && split) go(k_front2048<true, true, kRows2048L>);
+        else if (stereo) go(k_front2048<true, false, kRows2048L>);
+        else if (split) go(k_front2048<false, true, kRows2048L>);
+        else go(k_front2048<false, false, kRows2048L>);
+    } else {
+        if (stereo && split) go(k_front2048<true, true, kRows2048>);
+        else if (stereo) go(k_front2048<true, false, kRows2048>);
+        else if (split) go(k_front2048<false, true, kRows2048>);
+        else go(k_front2048<false, false, kRows2048>);
+    }
+    if (err != hipSuccess) return err;
     return hipGetLastError();
 }
 

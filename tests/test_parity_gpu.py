@@ -1544,7 +1544,7 @@ _F2048 = [  # W, S, sr, nb, nc, c0, dyn, channels, alpha
     (1102, 441, 44100.0, 128, 40, False, 2, 2, 1.0),     # configs[4] itself: stereo, odd shift
     (1102, 441, 44100.0, 128, 40, False, 2, 1, 1.0),     # mono at an odd shift: stays on k_front_reg (not aligned pairs)
     (1102, 440, 44100.0, 128, 40, False, 2, 1, 1.0),     # mono, aligned pairs
-    (1152, 400, 48000.0, 96, 24, True, 1, 2, 0.93),      # the longest window the kernel takes, c0, VTLN
+    (1152, 400, 48000.0, 96, 24, True, 1, 2, 0.93),      # the longest window of the 18-row build, c0, VTLN
     (1025, 512, 44100.0, 40, 13, False, 0, 2, 1.0),      # odd window length, few filters, one DCT tile
     (1100, 300, 32000.0, 200, 60, False, 2, 1, 1.07),    # 7 rounds of 32 filters, 4 DCT tiles; fewer waves per block (LDS)
     (1050, 350, 44100.0, 64, 0, False, 1, 2, 1.0),       # log mel energies as the features (no DCT)
@@ -1553,6 +1553,9 @@ _F2048 = [  # W, S, sr, nb, nc, c0, dyn, channels, alpha
     (1102, 440, 44100.0, 64, 39, True, 1, 1, 0.9),       # split DCT A + B at 64 bands (8 / 2 K-groups: the runtime-loop form), mono
     (1100, 320, 32000.0, 256, 33, False, 0, 2, 1.0),     # split DCT A + B at 256 bands, 33 columns: one column in pass B
     (1102, 441, 44100.0, 96, 32, False, 2, 2, 1.1),      # split DCT, pass A alone, exactly 32 columns, 96 bands
+    (1200, 480, 48000.0, 128, 40, False, 2, 2, 1.0),     # 25 ms at 48 kHz: the 20-row build (W <= 1280), stereo, split DCT
+    (1280, 480, 48000.0, 80, 13, False, 1, 1, 1.05),     # the longest window of the 20-row build, mono, one-tile DCT
+    (1153, 577, 48000.0, 40, 20, True, 0, 2, 1.0),       # one tap past the 18-row build, odd shift, stereo
 ]
 
 
