@@ -793,7 +793,7 @@ extern "C" int mfx_profile_read(mfx_handle *h, int32_t *launches, double *kernel
 extern "C" const char *mfx_dominant_kernel_name(const mfx_handle *h)
 {
     if (!h) return "";
-    if (h->fast2048 && h->wplan32_ok && (h->channels == 2 || ((h->S % 2) == 0 && (h->W % 2) == 0 && h->batch_aligned))) return "k_front2048";
+    if (h->fast2048 && h->wplan32_ok) return "k_front2048";
     return h->fast512 ? "k_front512" : (h->fast1024 && h->fused_ok && (h->W <= 512 || h->batch_aligned)) ? "k_front1024" : h->W2 >= 1024 ? "k_front_reg" : "k_front_wave"; // names as rocprofv3 prints them
 }
 
@@ -1617,7 +1617,7 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
     // (k_front2048: 12 waves per CU, each 16-frame chunk is 8 iterations of ~10 us -- on C5 a wave sees only ~4 chunks in
     // all, so the last ONE per wave is cut, and a launch twice that long already qualifies)
     const int ts = h->cfg.tail_split;
-    const bool f2048 = h->fast2048 && h->wplan32_ok && (h->channels == 2 || (aligned && (h->S % 2) == 0 && (h->W % 2) == 0));
+    const bool f2048 = h->fast2048 && h->wplan32_ok; // (stereo, mono on aligned pairs, mono at any alignment: all three builds)
     if ((h->fast512 || (h->fast1024 && h->fused_ok) || f2048) && ts >= 0) {
         const size_t n = h->h_chunks.size();
         const size_t tail = std::min<size_t>(n, (size_t)(ts > 0 ? std::min(ts, 64) : f2048 ? 1 : 2) * (f2048 ? 12 : 16) * h->num_cus);
@@ -1712,8 +1712,9 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
     const bool fused1024 = allow_fused && h->fast1024 && h->fused_ok && (h->W <= 512 || h->batch_aligned); // (long windows: aligned frames only)
     // (up to 2048 points the fused form saves the spectrum's round trip through HBM -- 8 KB per frame at 2048
     // points; at 4096 points the tables + per-wave buffers no longer leave enough waves per CU)
-    // (2048 points, window <= 1280 samples: two frames per wave; mono needs aligned sample pairs)
-    const bool fused2048 = allow_fused && h->fast2048 && h->wplan32_ok && (h->channels == 2 || p.pair_ok);
+    // (2048 points, window <= 1280 samples: two frames per wave; mono off the aligned sample pairs -- odd shifts such as
+    // 441 samples = 10 ms at 44.1 kHz, odd offsets -- takes the any-alignment build: two words per pair, funnel-shifted)
+    const bool fused2048 = allow_fused && h->fast2048 && h->wplan32_ok;
     const bool fusedgen = allow_fused && !fused512 && !fused1024 && !fused2048 && h->W2 <= 2048 && h->wplan_ok &&
                           front_wave_lds_bytes(p, true) <= 160 * 1024;
     // With deltas on, the front end writes its statics as compact 64-byte rows into a scratch buffer

@@ -123,11 +123,17 @@ __host__ __device__ inline size_t front2048_table_floats(int rounds, int row_str
 // SPLIT: the DCT in its split form (p.dct_split != 0: <= 40 columns, bands a multiple of 32) -- a build of its own, so that
 // neither form carries the other's code and scalar registers
 // NR: rows of 32 sample pairs that carry window taps (18: W <= 1152; 20: W <= 1280) -- the zero rows fold away at compile time
-template <bool STEREO, bool SPLIT, int NR>
+// CH: 0 = mono, frames on aligned sample pairs (even offsets, even shift: one 32-bit word per pair); 1 = interleaved stereo (one
+// word per sample, any alignment); 2 = mono at ANY alignment (odd shifts -- 441 samples = 10 ms at 44.1 kHz -- or odd
+// offsets): the two aligned words that cover a pair are loaded and funnel-shifted by the frame's parity
+template <int CH, bool SPLIT, int NR>
 __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(FrontParams p)
 {
     constexpr int M = 1024;
-    constexpr int NWORD = STEREO ? 2 * NR : NR; // raw 32-bit words per lane and frame
+    constexpr bool STEREO = CH == 1, ANY = CH == 2;
+    // depth of the DCT's operand ring: what the build's registers allow without a spill
+    constexpr int kRingSplit = (ANY || (STEREO && NR > kRows2048)) ? 5 : 7, kRingTile = ANY ? 5 : 7;
+    constexpr int NWORD = (STEREO || ANY) ? 2 * NR : NR; // raw 32-bit words per lane and frame
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
     const int l = lane & 31, half = lane >> 5;
@@ -192,6 +198,7 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
     struct ChunkCtx {
         int64_t out_row;
         int n_live;
+        int odd0; // ANY: the chunk starts on an odd sample (its descriptor on the even one before)
         __amdgpu_buffer_rsrc_t rsrc;
     };
     auto make_ctx = [&](int c) -> ChunkCtx {
@@ -204,7 +211,8 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
         const int64_t rows_left = p.row_limit - x.out_row;
         x.n_live = (int)(rows_left < n_frames ? (rows_left < 0 ? 0 : rows_left) : n_frames);
         // buffer descriptor over [chunk start, end of PCM): out-of-range lanes read 0 (whole 32-bit words: see k_front512)
-        const int64_t el0 = pcm_off * (STEREO ? 2 : 1);
+        x.odd0 = ANY ? (int)(pcm_off & 1) : 0;
+        const int64_t el0 = STEREO ? pcm_off * 2 : ANY ? (pcm_off & ~(int64_t)1) : pcm_off;
         int64_t bytes_left = valid ? (((p.pcm_total - el0) * 2 + 3) & ~(int64_t)3) : 0;
         if (bytes_left > 0xfffffff0ll) bytes_left = 0xfffffff0ll;
         if (bytes_left < 0) bytes_left = 0;
@@ -225,12 +233,13 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
     // raw words of (frame f, this lane): sample pair n = l + 32 j at byte (f S + 2 n) * (STEREO ? 4 : 2)
     uint32_t raw[NWORD];
     auto issue = [&](const ChunkCtx &x, int f) {
-        const int voff = (f * p.shift + 2 * l) * (STEREO ? 4 : 2);
+        // (ANY: the frame's first sample s = odd0 + f S rounded down to an even one; the pair's two words from there)
+        const int voff = ANY ? (((x.odd0 + f * p.shift) & ~1) + 2 * l) * 2 : (f * p.shift + 2 * l) * (STEREO ? 4 : 2);
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             // (the row's constant goes in as the scalar offset: added to the lane's offset by the address unit, no vector add)
-            if (STEREO) {
-                const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(x.rsrc, voff, 256 * j, 0);
+            if (STEREO || ANY) {
+                const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(x.rsrc, voff, (STEREO ? 256 : 128) * j, 0);
                 raw[2 * j] = d[0];
                 raw[2 * j + 1] = d[1];
             } else {
@@ -281,6 +290,8 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
 #endif
             // ---- framing + window: z[n2] = (w[2n] x[2n], w[2n+1] x[2n+1]), n = l + 32 n2
             float2 z[32];
+            // (ANY: the frame starts on an odd sample: its pair is the upper half of the first word and the lower half of the second)
+            const uint32_t par_shift = ANY ? (uint32_t)(((ccur.odd0 + f * p.shift) & 1) << 4) : 0u;
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
                 if (j >= NR) {
@@ -288,7 +299,11 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
                     continue;
                 }
                 float x0, x1;
-                if (STEREO) { // one 32-bit word per sample (L | R << 16); mono = (L + R) >> 1 as the reference driver's caller
+                if (ANY) {
+                    const uint32_t d = __builtin_amdgcn_alignbit(raw[2 * j + 1], raw[2 * j], par_shift);
+                    x0 = (float)(int)(short)(d & 0xffffu);
+                    x1 = (float)((int)d >> 16);
+                } else if (STEREO) { // one 32-bit word per sample (L | R << 16); mono = (L + R) >> 1 as the reference driver's caller
                     const uint32_t d0 = raw[2 * j], d1 = raw[2 * j + 1];
                     x0 = stereo_mean(d0);
                     x1 = stereo_mean(d1);
@@ -457,7 +472,7 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
                     // Pass A: lane = (band half kb = lane >> 5, column lane & 31); one instruction adds one band of EACH half.
                     const int nbk = p.num_banks;
                     float ra[4];
-                    dct_mfma4s<(STEREO && NR > kRows2048) ? 5 : 7>(lm + (lane & 3) * lmFS + (lane >> 5) * (nbk >> 1), dct_rsrc, dct_bytes, lane, 0, nbk >> 3, ra);
+                    dct_mfma4s<kRingSplit>(lm + (lane & 3) * lmFS + (lane >> 5) * (nbk >> 1), dct_rsrc, dct_bytes, lane, 0, nbk >> 3, ra);
                     // the halves meet: after the swap lanes 0..31 hold (frame 0 | frame 2), lanes 32..63 (frame 1 | frame 3)
                     const auto a01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ra[0]), __float_as_uint(ra[1]), false, false);
                     const auto a23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ra[2]), __float_as_uint(ra[3]), false, false);
@@ -489,7 +504,7 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
                     const float *arow = lm + (lane & 3) * lmFS;
                     for (int tile = 0; tile < dct_tiles64; ++tile) {
                         float res[4];
-                        dct_mfma4<7>(arow, dct_rsrc, dct_bytes, lane, tile, dct_ks, res);
+                        dct_mfma4<kRingTile>(arow, dct_rsrc, dct_bytes, lane, tile, dct_ks, res);
                         const int col = 64 * tile + lane;
                         if (col < p.cols) {
 #pragma unroll
@@ -558,8 +573,7 @@ size_t front2048_lds_bytes(const FrontParams &p)
 hipError_t launch_front2048(const FrontParams &p, int num_cus, hipStream_t stream)
 {
     if (p.n_chunks <= 0) return hipSuccess;
-    const bool stereo = p.channels == 2;
-    if (!stereo && !p.pair_ok) return hipErrorInvalidValue; // mono: aligned sample pairs only (others stay on k_front_reg)
+    const int ch = p.channels == 2 ? 1 : p.pair_ok ? 0 : 2; // (mono off the aligned pairs: the any-alignment build)
     const int nw = waves_2048(p);
     if (nw == 0) return hipErrorInvalidValue;
     const size_t lds = lds_bytes_2048(p, nw);
@@ -574,15 +588,13 @@ hipError_t launch_front2048(const FrontParams &p, int num_cus, hipStream_t strea
         if (err == hipSuccess) hipLaunchKernelGGL(kern, dim3(blocks), dim3(nw * 64), lds, stream, p);
     };
     if (wide) {
-        if (stereo && split) go(k_front2048<true, true, kRows2048L>);
-        else if (stereo) go(k_front2048<true, false, kRows2048L>);
-        else if (split) go(k_front2048<false, true, kRows2048L>);
-        else go(k_front2048<false, false, kRows2048L>);
+        if (ch == 1) { if (split) go(k_front2048<1, true, kRows2048L>); else go(k_front2048<1, false, kRows2048L>); }
+        else if (ch == 2) { if (split) go(k_front2048<2, true, kRows2048L>); else go(k_front2048<2, false, kRows2048L>); }
+        else { if (split) go(k_front2048<0, true, kRows2048L>); else go(k_front2048<0, false, kRows2048L>); }
     } else {
-        if (stereo && split) go(k_front2048<true, true, kRows2048>);
-        else if (stereo) go(k_front2048<true, false, kRows2048>);
-        else if (split) go(k_front2048<false, true, kRows2048>);
-        else go(k_front2048<false, false, kRows2048>);
+        if (ch == 1) { if (split) go(k_front2048<1, true, kRows2048>); else go(k_front2048<1, false, kRows2048>); }
+        else if (ch == 2) { if (split) go(k_front2048<2, true, kRows2048>); else go(k_front2048<2, false, kRows2048>); }
+        else { if (split) go(k_front2048<0, true, kRows2048>); else go(k_front2048<0, false, kRows2048>); }
     }
     if (err != hipSuccess) return err;
     return hipGetLastError();

@@ -1542,7 +1542,7 @@ def test_sliced_batch_then_large_streaming_download_on_one_handle(pkg, orc):
 
 _F2048 = [  # W, S, sr, nb, nc, c0, dyn, channels, alpha
     (1102, 441, 44100.0, 128, 40, False, 2, 2, 1.0),     # configs[4] itself: stereo, odd shift
-    (1102, 441, 44100.0, 128, 40, False, 2, 1, 1.0),     # mono at an odd shift: stays on k_front_reg (not aligned pairs)
+    (1102, 441, 44100.0, 128, 40, False, 2, 1, 1.0),     # mono at an odd shift (10 ms at 44.1 kHz): the any-alignment build
     (1102, 440, 44100.0, 128, 40, False, 2, 1, 1.0),     # mono, aligned pairs
     (1152, 400, 48000.0, 96, 24, True, 1, 2, 0.93),      # the longest window of the 18-row build, c0, VTLN
     (1025, 512, 44100.0, 40, 13, False, 0, 2, 1.0),      # odd window length, few filters, one DCT tile
@@ -1567,7 +1567,7 @@ def test_front2048_configurations(pkg, orc, W, S, sr, nb, nc, c0, dyn, ch, alpha
     factorisation of the same transform)."""
     rng = np.random.default_rng(W + S + nb)
     frames = [1, 2, 3, 15, 16, 17, 33, 70]
-    step = 2 if (ch == 1 and S % 2 == 0) else 1          # mono pairs: even offsets keep the aligned path
+    step = 2 if (ch == 1 and S % 2 == 0 and W % 2 == 0 and nb != 80) else 1   # mono pairs: even offsets keep the aligned build (the nb = 80 case: odd offsets at an even shift)
     lens = [(T - 1) * S + W + int(rng.integers(0, S)) for T in frames]
     offs, pos = [], 0
     for n in lens:
@@ -1596,8 +1596,7 @@ def test_front2048_configurations(pkg, orc, W, S, sr, nb, nc, c0, dyn, ch, alpha
     if alpha != 1.0:
         m.set_alpha(alpha)
     rows, total = m.batch_plan(offs, lens)
-    aligned = ch == 2 or (S % 2 == 0)
-    assert m.dominant_kernel_name() == ("k_front2048" if aligned else "k_front_reg")
+    assert m.dominant_kernel_name() == "k_front2048"
     got = m.batch_run_host(pcm)
     assert total == sum(frames) and got.shape[0] == total
     g = groups_of(dyn)

@@ -13,8 +13,9 @@ for case in range(n_cases):
     ch = int(rng.integers(1, 3))
     W = int(rng.integers(600, 1281))
     S = int(rng.integers(max(8, W // 6), W + 1))
-    if ch == 1:
-        W += W & 1      # mono: aligned sample pairs
+    even = ch == 1 and bool(rng.integers(0, 2))     # mono: half of the cases on aligned sample pairs, half at any alignment
+    if even:
+        W += W & 1
         S += S & 1
     nb = int(rng.choice([8, 15, 26, 40, 64, 80, 128, 200, 256, int(rng.integers(6, 257))]))
     c0 = bool(rng.integers(0, 2))
@@ -29,12 +30,12 @@ for case in range(n_cases):
     D = 0 if dyn == 0 else 2 if dyn == 1 else 4
     frames = [max(T, 2 * D + 1) for T in frames]
     lens = [(T - 1) * S + W + int(rng.integers(0, S)) for T in frames]
-    if ch == 1:
+    if even:
         lens = [n + (n & 1) for n in lens]
     offs, pos = [], 0
     for n in lens:
         offs.append(pos)
-        pos += n + 2 * int(rng.integers(0, 3))
+        pos += n + (2 * int(rng.integers(0, 3)) if (even or ch == 2) else int(rng.integers(0, 5)))
     pcm = (4000.0 * rng.standard_normal(pos * ch)).round().clip(-32768, 32767).astype(np.int16)
     outs = []
     try:
