@@ -1297,8 +1297,11 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
 //   else : magnitudes to the HBM spectrum buffer (streaming set_input).
 // ------------------------------------------------------------------------------------------------
 // G = threads that share one frame: 64 (a wave; wave-level synchronisation only).
+#ifndef MFX_WAVE_MINW
+#define MFX_WAVE_MINW 8 // waves per SIMD the register allocation aims at (8: 64 registers + 56 bytes of scratch, still 9 % faster than 5 / 6 resident blocks: profiles/r03/abx_front_wave_occupancy.txt)
+#endif
 template <bool FUSED, int G>
-__global__ void __launch_bounds__(256) k_front_wave(FrontParams p)
+__global__ void __launch_bounds__(256, MFX_WAVE_MINW) k_front_wave(FrontParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid / G, lane = tid % G; // 'wave' = frame group inside the block
@@ -2730,7 +2733,14 @@ hipError_t launch_front_generic(const FrontParams &p, bool fused, hipStream_t st
         if (e != hipSuccess) return e;
     }
     int blocks = (p.n_chunks + 3) / 4;
-    const int cap = num_cus() * 8;
+    // persistent blocks, as many as are RESIDENT at once (registers: 6 per CU for the fused build; the LDS may allow fewer): a
+    // grid of 8 per CU where 5 fit ran in two rounds -- 8 kHz / 256 points 2.46 ms per 2 M frames against 1.78 with 8 resident
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 4;
+    }
+    const int cap = num_cus() * (per_cu > 8 ? 8 : per_cu);
     if (blocks > cap) blocks = cap;
     if (fused)
         hipLaunchKernelGGL((k_front_wave<true, 64>), dim3(blocks), dim3(256), lds, stream, p);

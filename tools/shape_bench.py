@@ -15,7 +15,10 @@ SHAPES = [  # name, sr, W, S, nb, nc, channels, seconds, n_utt
     ("44.1 kHz mono, 25/10 ms, 2048-pt, 128 mel, 40 MFCC", 44100.0, 1102, 441, 128, 40, 1, 10, 200),
     ("48 kHz mono, 25/10 ms, 2048-pt, 128 mel, 40 MFCC", 48000.0, 1200, 480, 128, 40, 1, 10, 200),
 ]
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ""
 for name, sr, W, S, nb, nc, ch, sec, n_utt in SHAPES:
+    if ONLY and not name.startswith(ONLY):
+        continue
     n = int(sr * sec)
     n += n & 1
     m = pkg.MfccHip(n + 1000, W, S, nb, sr, 64.0, sr / 2, nc, False, 22.0, 0, 2, 3, 3, True, channels=ch)
