@@ -2769,7 +2769,13 @@ hipError_t launch_melcep(const MelcepParams &p, hipStream_t stream)
         if (e != hipSuccess) return e;
     }
     int64_t blocks = ((p.n_rows + 3) / 4 + nw - 1) / nw;
-    const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
+    // persistent blocks: as many as are resident at once (registers allow 6 blocks of 4 waves; see launch_front_generic)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_melcep, 64 * nw, lds) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = (int)std::min<size_t>(4, (160 * 1024) / lds);
+    }
+    if (per_cu > 8) per_cu = 8;
     const int cap = num_cus() * (per_cu < 1 ? 1 : per_cu);
     if (blocks > cap) blocks = cap;
     const int tables = p.n_tables > 1 ? p.n_tables : 1;
