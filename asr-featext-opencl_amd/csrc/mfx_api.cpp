@@ -66,6 +66,7 @@ struct mfx_handle {
     int spec_pitch = 0;
     int channels = 1;
     bool fast512 = false;
+    bool stuff256 = false; // fast512 serving 256-point transforms in the zero-stuffed form
     bool fast1024 = false; // 1024 points, window <= 512 samples: k_front1024 (two 256-point transforms per frame)
     int nm16 = 16;
     float alpha = 1.f, table_alpha = -1.f;
@@ -325,6 +326,7 @@ void fill_front(const mfx_handle *h, FrontParams &p)
     p.mel32_row_stride = h->wplan32_ok ? h->wplan32.row_stride : 0;
     for (int i = 0; i < 8; ++i) p.mel32_L[i] = h->wplan32.L[i];
     p.dct_b = h->ceps > 0 ? h->d_dct_b.p : nullptr;
+    p.stuff = h->stuff256 ? 1 : 0;
     p.dct_b4 = h->ceps > 0 ? h->d_dct_b4.p : nullptr;
     p.dct_b4s = (h->ceps > 0 && h->dct_split) ? h->d_dct_b4s.p : nullptr;
     p.dct_split = h->ceps > 0 ? h->dct_split : 0;
@@ -579,7 +581,8 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
         return MFX_ERR_CONFIG;
     }
     h->spec_pitch = ((h->W2 / 2 + 1) + 3) & ~3;
-    h->fast512 = front512_supported(h->W2, h->W, h->nb, h->cols, h->channels);
+    h->fast512 = front512_supported(h->W2, h->W, h->nb, h->cols, h->channels) && !(h->W2 == 256 && (h->cfg.engine & MFX_ENGINE_NO_STUFF256));
+    h->stuff256 = h->fast512 && h->W2 == 256;
     h->fast2048 = !(h->cfg.engine & MFX_ENGINE_NO_FRONT2048) && front2048_supported(h->W2, h->W, h->nb, h->cols, h->channels);
     h->fast1024 = !(h->cfg.engine & MFX_ENGINE_NO_FRONT1024) &&
                   front1024_supported(h->W2, h->W, h->nb, h->cols, h->channels, h->ceps);
@@ -589,7 +592,7 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
             h->num_cus = prop.multiProcessorCount;
         h->fuse_delta_enabled = (h->cfg.engine & MFX_ENGINE_FUSE_DELTA) != 0;
     }
-    h->nm16 = (h->W + 31) / 32;
+    h->nm16 = h->stuff256 ? (h->W + 15) / 16 : (h->W + 31) / 32; // rows of the frame that carry window taps
 
     int rc = MFX_OK;
     auto bail = [&](int code) {
@@ -861,6 +864,10 @@ extern "C" int mfx_set_window(mfx_handle *h, const float *window)
         for (int l = 0; l < 16; ++l)
             for (int m = 0; m < 16; ++m) {
                 int n = l + 16 * m;
+                if (h->stuff256) { // zero-stuffed 256-point form: packed sample n = (x[n], 0)
+                    wp[2 * (l * 16 + m)] = padded[n] * fold;
+                    continue;
+                }
                 wp[2 * (l * 16 + m)] = padded[2 * n] * fold;
                 wp[2 * (l * 16 + m) + 1] = padded[2 * n + 1] * fold;
             }
@@ -1426,7 +1433,7 @@ int plan_fused_delta(mfx_handle *h, const std::vector<int64_t> &T_of)
 {
     h->fuse_plan = false;
     const size_t n = h->h_chunks.size();
-    if (!h->fuse_delta_enabled || !h->fast512 || h->l1 <= 0 || h->cols > 16 || h->ceps <= 0 || h->D > 16 || n == 0 ||
+    if (!h->fuse_delta_enabled || !h->fast512 || h->stuff256 || h->l1 <= 0 || h->cols > 16 || h->ceps <= 0 || h->D > 16 || n == 0 ||
         n > 0x3fffffff || (h->cfg.norm != MFX_NORM_NONE && !h->cfg.norm_after_dyn))
         return MFX_OK;
     const int D = h->D;

@@ -99,6 +99,15 @@ __device__ __forceinline__ void pcm_issue(PcmRegs<ALIGNED, NM> &r, __amdgpu_buff
     }
 }
 
+// The zero-stuffed form (256-point transforms on the 512-point core, k_front512<.., STUFF>): ONE sample per lane and row,
+// 16 samples per row; `voff` = byte offset of this lane's first sample
+template <int NM>
+__device__ __forceinline__ void pcm_issue_stuffed(PcmRegs<true, NM> &r, __amdgpu_buffer_rsrc_t rsrc, int voff)
+{
+#pragma unroll
+    for (int m = 0; m < NM; ++m) r.d[m] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, 32 * m, 0);
+}
+
 // Dev-only in-kernel stamps (-DMFX_STAMPS): per-wave cycle sums per phase, written by lane 0 to
 // p.spec (which is unused by the fused path).  Never part of a timed build.
 #ifdef MFX_STAMPS
@@ -359,7 +368,11 @@ __device__ __forceinline__ void delta_tile16(const Segment &sg, int r0, int rows
     PSTAMP(3);
 }
 
-template <bool ALIGNED, bool TO_SPEC, int NM, bool FUSE>
+// STUFF: a 256-POINT transform on this core.  The 512-point real DFT of the frame with a zero after every sample,
+// y[2n] = x[n], y[2n+1] = 0, is X_256[k mod 256]: the packed sequence is z[n] = x[n] + 0i, one sample per lane and row (16-bit
+// loads, 16 samples per row, any alignment), and bins 0 .. 128 of the result are the 256-point spectrum -- the same arithmetic
+// at the cost of a 512-point frame, where the one-wave-per-frame kernel took 2.6 x as long (8 kHz telephony, 200-tap windows).
+template <bool ALIGNED, bool TO_SPEC, int NM, bool FUSE, bool STUFF = false>
 __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 waves per SIMD whatever the block size)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -537,8 +550,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
         const int64_t rows_left = p.row_limit - x.out_row;
         x.n_live = (int)(rows_left < n_frames ? (rows_left < 0 ? 0 : rows_left) : n_frames);
         // buffer descriptor over [chunk start, end of PCM): out-of-range lanes read 0
-        const int64_t base_s = ALIGNED ? pcm_off : (pcm_off & ~(int64_t)1);
-        x.odd0 = ALIGNED ? 0 : (int)(pcm_off & 1);
+        const int64_t base_s = (ALIGNED && !STUFF) ? pcm_off : (pcm_off & ~(int64_t)1);
+        x.odd0 = (ALIGNED && !STUFF) ? 0 : (int)(pcm_off & 1);
         // (rounded up to whole 32-bit words: with an odd sample count the array's last sample sits in a word whose
         // upper half lies past the end, and the range check would drop the whole word -- the base is 4-byte aligned,
         // so that word is inside the allocation, and the half past the end only ever meets a zero window tap)
@@ -554,6 +567,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
     };
     // byte offset of (frame f, sample pair l) relative to the chunk's descriptor base
     auto lane_off = [&](const ChunkCtx &x, int f) -> int {
+        if (STUFF) return (x.odd0 + f * p.shift + l) * 2; // (one sample per lane)
         const int s = x.odd0 + f * p.shift + 2 * l;
         return ALIGNED ? s * 2 : (s & ~1) * 2;
     };
@@ -575,8 +589,14 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
     int c_nxt = chunk_of(__builtin_amdgcn_readfirstlane(v_b));
     ChunkCtx ccur = make_ctx(c_cur);
     ChunkCtx cnxt = make_ctx(c_nxt);
-    PcmRegs<ALIGNED, NM> cur;
-    pcm_issue<ALIGNED, NM>(cur, ccur.rsrc, lane_off(ccur, slot));
+    PcmRegs<ALIGNED || STUFF, NM> cur;
+    auto issue = [&](__amdgpu_buffer_rsrc_t rsrc, int voff) {
+        if constexpr (STUFF)
+            pcm_issue_stuffed<NM>(cur, rsrc, voff);
+        else
+            pcm_issue<ALIGNED, NM>(cur, rsrc, voff);
+    };
+    issue(ccur.rsrc, lane_off(ccur, slot));
 
     while (c_cur < p.n_chunks) {
         const int64_t out_row = ccur.out_row;
@@ -590,7 +610,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
             MFX_STAMP(0);
             // ---- framing + window: z[l + 16m] = (w[2n] x[2n], w[2n+1] x[2n+1])
             float2 a[16];
-            const bool odd = !ALIGNED && ((odd0 + f * p.shift) & 1);
+            const bool odd = !ALIGNED && !STUFF && ((odd0 + f * p.shift) & 1);
             float4 wq[(NM + 1) / 2];
 #pragma unroll
             for (int m = 0; m < (NM + 1) / 2; ++m) wq[m] = ((const float4 *)(s_win + l * kTabStride))[m];
@@ -598,7 +618,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
             for (int m = 0; m < 16; ++m) {
                 if (m < NM) {
                     uint32_t d;
-                    if (ALIGNED) {
+                    if (ALIGNED || STUFF) {
                         d = cur.d[m];
                     } else {
                         const uint32_t d0 = cur.d[2 * m], d1 = cur.d[2 * m + 1];
@@ -607,7 +627,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
                     const float x0 = (float)(int)(short)(d & 0xffffu);
                     const float x1 = (float)((int)d >> 16);
                     const float2 w = (m & 1) ? make_float2(wq[m >> 1].z, wq[m >> 1].w) : make_float2(wq[m >> 1].x, wq[m >> 1].y);
-                    a[m] = make_float2(w.x * x0, w.y * x1);
+                    a[m] = STUFF ? make_float2(w.x * x0, 0.f) : make_float2(w.x * x0, w.y * x1);
                 } else {
                     a[m] = make_float2(0.f, 0.f);
                 }
@@ -616,7 +636,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
             // Prefetch into the registers just consumed, unconditionally (a conditional issue would make
             // the number of loads in flight path-dependent and force a vmcnt(0) wait): the next 4 frames
             // of this chunk or, from the chunk's last iteration, the first 4 frames of the next chunk.
-            pcm_issue<ALIGNED, NM>(cur, last ? cnxt.rsrc : ccur.rsrc, last ? lane_off(cnxt, slot) : lane_off(ccur, f + 4));
+            issue(last ? cnxt.rsrc : ccur.rsrc, last ? lane_off(cnxt, slot) : lane_off(ccur, f + 4));
 
             MFX_STAMP(1);
             // ---- pass A + inter-pass twiddle
@@ -699,7 +719,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
 #pragma unroll
                     for (int pp = 0; pp < 8; ++pp) {
                         dst[l + 16 * pp] = mag_k[pp];
-                        dst[256 - l - 16 * pp] = mag_p[pp];
+                        if (!STUFF) dst[256 - l - 16 * pp] = mag_p[pp]; // (STUFF: a row holds bins 0 .. 128 of the 256-point transform)
                     }
                     if (l == 0) dst[128] = mag128;
                 }
@@ -866,7 +886,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
             }
             MFX_STAMP(6);
         }
-        if (n_live <= 0) pcm_issue<ALIGNED, NM>(cur, cnxt.rsrc, lane_off(cnxt, slot)); // empty chunk: nothing was prefetched
+        if (n_live <= 0) issue(cnxt.rsrc, lane_off(cnxt, slot)); // empty chunk: nothing was prefetched
         if (FUSE) { // the chunk's statics are on their way to memory: publish it to the delta wave
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             const int kk = c_cur - chunk_base;
@@ -2514,7 +2534,7 @@ hipError_t launch512_delta(const FrontParams &p, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <bool A, bool S, int NM>
+template <bool A, bool S, int NM, bool STUFF = false>
 hipError_t launch512(const FrontParams &p_in, hipStream_t stream)
 {
     FrontParams p = p_in;
@@ -2526,7 +2546,7 @@ hipError_t launch512(const FrontParams &p_in, hipStream_t stream)
     }
     const size_t lds = front512_lds_bytes(p);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_front512<A, S, NM, false>,
+        hipError_t e = hipFuncSetAttribute((const void *)k_front512<A, S, NM, false, STUFF>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
@@ -2535,7 +2555,7 @@ hipError_t launch512(const FrontParams &p_in, hipStream_t stream)
     const int cap = num_cus() * (32 / kWaves) / 2; // 16 waves per CU
     int blocks = p.n_chunks < cap ? p.n_chunks : cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_front512<A, S, NM, false>), dim3(blocks), dim3(kThreads), lds, stream, p);
+    hipLaunchKernelGGL((k_front512<A, S, NM, false, STUFF>), dim3(blocks), dim3(kThreads), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -2588,7 +2608,8 @@ hipError_t launch_front1024(const FrontParams &p, bool aligned, int nm16, hipStr
 
 bool front512_supported(int fft_size, int window_size, int num_banks, int cols, int channels)
 {
-    return fft_size == 512 && window_size <= 512 && window_size > 0 && channels <= 1 && num_banks >= 1 &&
+    // (256 points: the zero-stuffed form of the same kernel, FrontParams::stuff)
+    return (fft_size == 512 || fft_size == 256) && window_size <= fft_size && window_size > 0 && channels <= 1 && num_banks >= 1 &&
            num_banks <= 128 && cols <= 128;
 }
 
@@ -2605,6 +2626,10 @@ hipError_t launch_front512(const FrontParams &p, bool to_spectrum, bool aligned,
     if (p.n_chunks <= 0) return hipSuccess;
     // NM = number of 32-sample rows that carry window taps: 13 covers W <= 416 (25 ms at 16 kHz)
     const bool nm13 = nm16 <= 13;
+    if (p.stuff) { // 256-point transforms, zero-stuffed: nm16 = rows of 16 samples (200 taps: 13)
+        if (to_spectrum) return nm13 ? launch512<true, true, 13, true>(p, stream) : launch512<true, true, 16, true>(p, stream);
+        return nm13 ? launch512<true, false, 13, true>(p, stream) : launch512<true, false, 16, true>(p, stream);
+    }
     if (to_spectrum) {
         if (aligned) return nm13 ? launch512<true, true, 13>(p, stream) : launch512<true, true, 16>(p, stream);
         return nm13 ? launch512<false, true, 13>(p, stream) : launch512<false, true, 16>(p, stream);

@@ -208,7 +208,7 @@ def reference_window(window_size):
 
 
 ENGINE_NO_FRONT1024, ENGINE_FUSE_DELTA, ENGINE_NO_FRONT2048, ENGINE_STREAM_KERNELS, ENGINE_NORM_TWO_KERNELS = 1, 2, 4, 8, 16
-ENGINE_DMA_SMALL_BLOCKS, ENGINE_NO_DCT_SPLIT = 32, 64     # mfx_config.engine bits (include/mfx.h)
+ENGINE_DMA_SMALL_BLOCKS, ENGINE_NO_DCT_SPLIT, ENGINE_NO_STUFF256 = 32, 64, 128     # mfx_config.engine bits (include/mfx.h)
 
 
 class MfccHip:

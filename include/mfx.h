@@ -103,6 +103,8 @@ typedef struct mfx_config {
                                            instead of by a copy kernel through the pinned staging buffers                 */
 #define MFX_ENGINE_NO_DCT_SPLIT 64      /* 2048-point fused kernel: the DCT as one 64-column tile also where at most 40 columns
                                            are wanted (else: column groups x band parts, summed across the wave)          */
+#define MFX_ENGINE_NO_STUFF256 128      /* 256-point transforms stay on the one-wave-per-frame kernel instead of the zero-stuffed
+                                           form of the 512-point kernel                                                   */
 
 typedef struct mfx_handle mfx_handle;
 

@@ -1623,6 +1623,79 @@ def test_front2048_configurations(pkg, orc, W, S, sr, nb, nc, c0, dyn, ch, alpha
     assert_close(got, m3.batch_run_host(pcm), "k_front2048 split DCT vs one tile", groups=g)
 
 
+_F256 = [  # W, S, sr, nb, nc, c0, dyn, alpha
+    (200, 80, 8000.0, 23, 13, False, 2, 1.0),      # 8 kHz telephony: 25 ms / 10 ms, 13 rows of 16 samples
+    (200, 81, 8000.0, 23, 12, True, 2, 1.0),       # odd shift: frames at odd sample offsets (16-bit loads: any alignment)
+    (256, 100, 8000.0, 40, 13, False, 1, 0.92),    # the longest window of a 256-point transform: 16 rows; VTLN
+    (129, 64, 8000.0, 15, 0, False, 0, 1.0),       # the shortest window that still takes 256 points; log mel energies
+    (220, 110, 11025.0, 26, 20, False, 2, 1.1),    # 20 columns: the LDS mat-vec DCT of the 512-point kernel (cols > 16)
+]
+
+
+@pytest.mark.parametrize("W,S,sr,nb,nc,c0,dyn,alpha", _F256)
+def test_front256_zero_stuffed_on_the_512_point_kernel(pkg, orc, W, S, sr, nb, nc, c0, dyn, alpha):
+    """256-point transforms run on k_front512 in its zero-stuffed form (the 512-point real DFT of x[0], 0, x[1], 0, ... is
+    X_256[k mod 256]).  Ragged utterances at odd and even offsets through the batch entry against the oracle fed each
+    utterance alone (the reference's 256-point path: mfcccpu.cpp:187-220), against the one-wave-per-frame kernel
+    (mfx_config.engine = MFX_ENGINE_NO_STUFF256), and the streaming interface (spectrum through HBM) block by block."""
+    rng = np.random.default_rng(W + S + nb)
+    frames = [1, 2, 3, 4, 5, 17, 64, 131]
+    lens = [(T - 1) * S + W + int(rng.integers(0, S)) for T in frames]
+    offs, pos = [], int(rng.integers(0, 3))
+    for n in lens:
+        offs.append(pos)
+        pos += n + int(rng.integers(0, 4))
+    pcm = np.zeros(pos, np.int16)
+    for i, (o_, n) in enumerate(zip(offs, lens)):
+        pcm[o_:o_ + n] = synth_utterance(n, 900 + i, sr=sr)
+    kw = dict(W=W, S=S, nb=nb, sr=sr, nc=nc, c0=c0, dyn=dyn, l1=2, l2=2)
+    m, cfg, w = make_pair(pkg, orc, max(lens) + 2000, **kw)
+    assert m.fft_size() == 256 and m.dominant_kernel_name() == "k_front512"
+    if alpha != 1.0:
+        m.set_alpha(alpha)
+    rows, total = m.batch_plan(offs, lens)
+    got = m.batch_run_host(pcm)
+    assert total == sum(frames) and got.shape[0] == total and np.isfinite(got).all()
+    g = groups_of(dyn)
+    m2, _, _ = make_pair(pkg, orc, max(lens) + 2000, engine=pkg.mfcc.ENGINE_NO_STUFF256, **kw)
+    assert m2.dominant_kernel_name() == "k_front_wave"
+    if alpha != 1.0:
+        m2.set_alpha(alpha)
+    m2.batch_plan(offs, lens)
+    assert_close(got, m2.batch_run_host(pcm), "zero-stuffed k_front512 vs k_front_wave", groups=g)
+    D = (2 + (2 if dyn == 2 else 0)) if dyn else 0
+    for i, (o_, n, T) in enumerate(zip(offs, lens, frames)):
+        if T <= 2 * D:
+            continue   # files of fewer than 2 D frames: the streaming reference refuses them or leaves its frame grid (DESIGN.md)
+        want = orc.run_utterance(cfg, pcm[o_:o_ + n], w, alpha=alpha, bug_compat=False)
+        assert want.shape[0] == T
+        assert_close(got[rows[i]:rows[i] + T], want, "utterance %d (%d frames)" % (i, T), groups=g)
+    # streaming interface on the longest utterance, odd block lengths
+    u = int(np.argmax(lens))
+    x = pcm[offs[u]:offs[u] + lens[u]]
+    ms, cfg_s, w_s = make_pair(pkg, orc, 4000, **kw)
+    o = orc.OracleMfcc(cfg_s, w_s)
+    if alpha != 1.0:
+        ms.set_alpha(alpha)
+        o.set_alpha(alpha)
+    a_rows, b_rows, p0 = [], [], 0
+    lim = ms.get_input_buffer_size()
+    while p0 < x.size:
+        b = min(lim - (p0 % 7), x.size - p0)
+        n, no = ms.set_input(x[p0:p0 + b]), o.set_input(x[p0:p0 + b])
+        assert n == no
+        p0 += b
+        if n > 0:
+            ms.apply(); o.apply()
+            a_rows.append(ms.get_output_data(n)); b_rows.append(o.get_output_data(n))
+    n, no = ms.flush(), o.flush()
+    assert n == no
+    if n > 0:
+        ms.apply(); o.apply()
+        a_rows.append(ms.get_output_data(n)); b_rows.append(o.get_output_data(n))
+    assert_close(np.concatenate(a_rows), np.concatenate(b_rows), "streaming, 256 points", groups=g)
+
+
 def test_c5_full_size_properties(pkg, orc):
     """BASELINE configs[4] at full size on one GPU: 200 stereo utterances x 10 s at 44.1 kHz (441 000 samples per channel)
     -> 199 600 frames x 120.  Every row written and finite, duplicate utterances give the same bits wherever they sit,
