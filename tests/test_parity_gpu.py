@@ -1777,6 +1777,35 @@ def test_cpp_driver_batches_are_byte_identical_to_the_per_file_loop(tmp_path, op
     assert mixed == mixed_loop
 
 
+def test_cpp_driver_8khz_files_batches_identical_to_the_loop(tmp_path):
+    """8 kHz files (256-point transforms: the zero-stuffed form of k_front512 in both the batch entry's streaming-kernel
+    engine and the per-file loop): batches and loop write the same bytes, and the rows equal the Python streaming path's."""
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "asr-featext-opencl_amd", "host", "afet_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    lens = [8000, 12345, 30001, 4000, 16000]
+    for i, n in enumerate(lens):
+        data = synth_utterance(n, 300 + i, sr=8000.0).astype("<i2").tobytes()
+        hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack(
+            "<IHHIIHH", 16, 1, 1, 8000, 16000, 2, 16) + b"data" + struct.pack("<I", len(data))
+        open(tmp_path / ("u%d.wav" % i), "wb").write(hdr + data)
+    opts = ["--high-freq", "4000", "--banks", "23", "--ceps", "13", "--c0", "0", "--norm", "0", "--dyn", "2", "--htk"]
+
+    def run(tag, extra):
+        args = []
+        for i in range(len(lens)):
+            args += [str(tmp_path / ("u%d.wav" % i)), str(tmp_path / ("%s_%d.htk" % (tag, i)))]
+        subprocess.check_call([exe] + opts + extra + args, stdout=subprocess.DEVNULL)
+        return [open(tmp_path / ("%s_%d.htk" % (tag, i)), "rb").read() for i in range(len(lens))]
+
+    loop = run("loop", ["--batch-mb", "0"])
+    batch = run("batch", [])
+    assert all(len(t) > 1000 for t in loop) and batch == loop
+
+
 def test_cpp_driver_multichannel_downmix_policy(orc, a0001, tmp_path):
     """ONE multi-channel policy across the product, pinned here so it cannot drift: mono = (L + R) >> 1 in integer
     arithmetic over the FIRST TWO channels (the batch kernels' channels = 2 downmix; further channels are ignored).  The
