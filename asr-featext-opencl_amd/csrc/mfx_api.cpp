@@ -1433,7 +1433,7 @@ int plan_fused_delta(mfx_handle *h, const std::vector<int64_t> &T_of)
 {
     h->fuse_plan = false;
     const size_t n = h->h_chunks.size();
-    if (!h->fuse_delta_enabled || !h->fast512 || h->stuff256 || h->l1 <= 0 || h->cols > 16 || h->ceps <= 0 || h->D > 16 || n == 0 ||
+    if (!h->fuse_delta_enabled || !h->fast512 || h->stuff256 || h->channels != 1 || h->l1 <= 0 || h->cols > 16 || h->ceps <= 0 || h->D > 16 || n == 0 ||
         n > 0x3fffffff || (h->cfg.norm != MFX_NORM_NONE && !h->cfg.norm_after_dyn))
         return MFX_OK;
     const int D = h->D;

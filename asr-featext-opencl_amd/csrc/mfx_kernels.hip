@@ -372,7 +372,9 @@ __device__ __forceinline__ void delta_tile16(const Segment &sg, int r0, int rows
 // y[2n] = x[n], y[2n+1] = 0, is X_256[k mod 256]: the packed sequence is z[n] = x[n] + 0i, one sample per lane and row (16-bit
 // loads, 16 samples per row, any alignment), and bins 0 .. 128 of the result are the 256-point spectrum -- the same arithmetic
 // at the cost of a 512-point frame, where the one-wave-per-frame kernel took 2.6 x as long (8 kHz telephony, 200-tap windows).
-template <bool ALIGNED, bool TO_SPEC, int NM, bool FUSE, bool STUFF = false>
+// CH2: interleaved stereo input (one 32-bit word per sample, L | R << 16; mono = (L + R) >> 1 as everywhere, stereo_mean): a
+// pair is one 8-byte load at any sample offset (STUFF: one word per lane and row)
+template <bool ALIGNED, bool TO_SPEC, int NM, bool FUSE, bool STUFF = false, bool CH2 = false>
 __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 waves per SIMD whatever the block size)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -550,8 +552,9 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
         const int64_t rows_left = p.row_limit - x.out_row;
         x.n_live = (int)(rows_left < n_frames ? (rows_left < 0 ? 0 : rows_left) : n_frames);
         // buffer descriptor over [chunk start, end of PCM): out-of-range lanes read 0
-        const int64_t base_s = (ALIGNED && !STUFF) ? pcm_off : (pcm_off & ~(int64_t)1);
-        x.odd0 = (ALIGNED && !STUFF) ? 0 : (int)(pcm_off & 1);
+        // (CH2: p.pcm_total counts int16 elements, two per sample; every sample is a whole, aligned word)
+        const int64_t base_s = CH2 ? pcm_off * 2 : (ALIGNED && !STUFF) ? pcm_off : (pcm_off & ~(int64_t)1);
+        x.odd0 = (CH2 || (ALIGNED && !STUFF)) ? 0 : (int)(pcm_off & 1);
         // (rounded up to whole 32-bit words: with an odd sample count the array's last sample sits in a word whose
         // upper half lies past the end, and the range check would drop the whole word -- the base is 4-byte aligned,
         // so that word is inside the allocation, and the half past the end only ever meets a zero window tap)
@@ -567,6 +570,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
     };
     // byte offset of (frame f, sample pair l) relative to the chunk's descriptor base
     auto lane_off = [&](const ChunkCtx &x, int f) -> int {
+        if (CH2) return (f * p.shift + (STUFF ? l : 2 * l)) * 4;
         if (STUFF) return (x.odd0 + f * p.shift + l) * 2; // (one sample per lane)
         const int s = x.odd0 + f * p.shift + 2 * l;
         return ALIGNED ? s * 2 : (s & ~1) * 2;
@@ -589,12 +593,24 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
     int c_nxt = chunk_of(__builtin_amdgcn_readfirstlane(v_b));
     ChunkCtx ccur = make_ctx(c_cur);
     ChunkCtx cnxt = make_ctx(c_nxt);
-    PcmRegs<ALIGNED || STUFF, NM> cur;
+    constexpr bool kOneWord = STUFF || (ALIGNED && !CH2); // registers per row: one word, or two (unaligned mono, stereo pairs)
+    PcmRegs<kOneWord, NM> cur;
     auto issue = [&](__amdgpu_buffer_rsrc_t rsrc, int voff) {
-        if constexpr (STUFF)
+        if constexpr (CH2 && STUFF) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) cur.d[m] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 64 * m, 0);
+        } else if constexpr (CH2) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 128 * m, 0);
+                cur.d[2 * m] = d[0];
+                cur.d[2 * m + 1] = d[1];
+            }
+        } else if constexpr (STUFF) {
             pcm_issue_stuffed<NM>(cur, rsrc, voff);
-        else
+        } else {
             pcm_issue<ALIGNED, NM>(cur, rsrc, voff);
+        }
     };
     issue(ccur.rsrc, lane_off(ccur, slot));
 
@@ -610,22 +626,30 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
             MFX_STAMP(0);
             // ---- framing + window: z[l + 16m] = (w[2n] x[2n], w[2n+1] x[2n+1])
             float2 a[16];
-            const bool odd = !ALIGNED && !STUFF && ((odd0 + f * p.shift) & 1);
+            const bool odd = !ALIGNED && !STUFF && !CH2 && ((odd0 + f * p.shift) & 1);
             float4 wq[(NM + 1) / 2];
 #pragma unroll
             for (int m = 0; m < (NM + 1) / 2; ++m) wq[m] = ((const float4 *)(s_win + l * kTabStride))[m];
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 if (m < NM) {
-                    uint32_t d;
-                    if (ALIGNED || STUFF) {
-                        d = cur.d[m];
+                    float x0, x1 = 0.f;
+                    if constexpr (CH2 && STUFF) {
+                        x0 = stereo_mean(cur.d[m]);
+                    } else if constexpr (CH2) {
+                        x0 = stereo_mean(cur.d[2 * m]);
+                        x1 = stereo_mean(cur.d[2 * m + 1]);
                     } else {
-                        const uint32_t d0 = cur.d[2 * m], d1 = cur.d[2 * m + 1];
-                        d = odd ? ((d0 >> 16) | (d1 << 16)) : d0;
+                        uint32_t d;
+                        if constexpr (ALIGNED || STUFF) {
+                            d = cur.d[m];
+                        } else {
+                            const uint32_t d0 = cur.d[2 * m], d1 = cur.d[2 * m + 1];
+                            d = odd ? ((d0 >> 16) | (d1 << 16)) : d0;
+                        }
+                        x0 = (float)(int)(short)(d & 0xffffu);
+                        x1 = (float)((int)d >> 16);
                     }
-                    const float x0 = (float)(int)(short)(d & 0xffffu);
-                    const float x1 = (float)((int)d >> 16);
                     const float2 w = (m & 1) ? make_float2(wq[m >> 1].z, wq[m >> 1].w) : make_float2(wq[m >> 1].x, wq[m >> 1].y);
                     a[m] = STUFF ? make_float2(w.x * x0, 0.f) : make_float2(w.x * x0, w.y * x1);
                 } else {
@@ -2534,7 +2558,7 @@ hipError_t launch512_delta(const FrontParams &p, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <bool A, bool S, int NM, bool STUFF = false>
+template <bool A, bool S, int NM, bool STUFF = false, bool CH2 = false>
 hipError_t launch512(const FrontParams &p_in, hipStream_t stream)
 {
     FrontParams p = p_in;
@@ -2546,7 +2570,7 @@ hipError_t launch512(const FrontParams &p_in, hipStream_t stream)
     }
     const size_t lds = front512_lds_bytes(p);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_front512<A, S, NM, false, STUFF>,
+        hipError_t e = hipFuncSetAttribute((const void *)k_front512<A, S, NM, false, STUFF, CH2>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
@@ -2555,7 +2579,7 @@ hipError_t launch512(const FrontParams &p_in, hipStream_t stream)
     const int cap = num_cus() * (32 / kWaves) / 2; // 16 waves per CU
     int blocks = p.n_chunks < cap ? p.n_chunks : cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_front512<A, S, NM, false, STUFF>), dim3(blocks), dim3(kThreads), lds, stream, p);
+    hipLaunchKernelGGL((k_front512<A, S, NM, false, STUFF, CH2>), dim3(blocks), dim3(kThreads), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -2609,7 +2633,7 @@ hipError_t launch_front1024(const FrontParams &p, bool aligned, int nm16, hipStr
 bool front512_supported(int fft_size, int window_size, int num_banks, int cols, int channels)
 {
     // (256 points: the zero-stuffed form of the same kernel, FrontParams::stuff)
-    return (fft_size == 512 || fft_size == 256) && window_size <= fft_size && window_size > 0 && channels <= 1 && num_banks >= 1 &&
+    return (fft_size == 512 || fft_size == 256) && window_size <= fft_size && window_size > 0 && channels <= 2 && num_banks >= 1 &&
            num_banks <= 128 && cols <= 128;
 }
 
@@ -2626,6 +2650,14 @@ hipError_t launch_front512(const FrontParams &p, bool to_spectrum, bool aligned,
     if (p.n_chunks <= 0) return hipSuccess;
     // NM = number of 32-sample rows that carry window taps: 13 covers W <= 416 (25 ms at 16 kHz)
     const bool nm13 = nm16 <= 13;
+    if (p.channels == 2) { // interleaved stereo (any offsets): nm16 = rows that carry taps, of 16 (stuffed) or 32 samples
+        if (p.stuff) {
+            if (to_spectrum) return nm13 ? launch512<true, true, 13, true, true>(p, stream) : launch512<true, true, 16, true, true>(p, stream);
+            return nm13 ? launch512<true, false, 13, true, true>(p, stream) : launch512<true, false, 16, true, true>(p, stream);
+        }
+        if (to_spectrum) return nm13 ? launch512<true, true, 13, false, true>(p, stream) : launch512<true, true, 16, false, true>(p, stream);
+        return nm13 ? launch512<true, false, 13, false, true>(p, stream) : launch512<true, false, 16, false, true>(p, stream);
+    }
     if (p.stuff) { // 256-point transforms, zero-stuffed: nm16 = rows of 16 samples (200 taps: 13)
         if (to_spectrum) return nm13 ? launch512<true, true, 13, true>(p, stream) : launch512<true, true, 16, true>(p, stream);
         return nm13 ? launch512<true, false, 13, true>(p, stream) : launch512<true, false, 16, true>(p, stream);

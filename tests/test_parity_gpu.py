@@ -1696,6 +1696,50 @@ def test_front256_zero_stuffed_on_the_512_point_kernel(pkg, orc, W, S, sr, nb, n
     assert_close(np.concatenate(a_rows), np.concatenate(b_rows), "streaming, 256 points", groups=g)
 
 
+@pytest.mark.parametrize("W,S,sr,nb,nc,dyn", [
+    (400, 160, 16000.0, 40, 13, 2),     # 16 kHz stereo: the 512-point kernel, one 8-byte load per sample pair
+    (400, 161, 16000.0, 26, 13, 0),     # odd shift (words are per sample: no alignment cases)
+    (512, 200, 16000.0, 40, 20, 1),     # the longest window, 16 rows, 20 columns
+    (200, 80, 8000.0, 23, 13, 2),       # 8 kHz stereo (two-channel call recordings): zero-stuffed, one word per lane and row
+    (256, 99, 8000.0, 15, 12, 0),
+])
+def test_front512_stereo_batches(pkg, orc, W, S, sr, nb, nc, dyn):
+    """Interleaved stereo through the batch entry on k_front512 (512 points, and 256 points zero-stuffed): mono =
+    (L + R) >> 1 in the kernel.  Ragged utterances at arbitrary sample offsets against the oracle fed the host-side
+    downmix, and the same extractor fed that downmix as mono input (float32 rounding apart: other load paths)."""
+    rng = np.random.default_rng(W + S + nb)
+    frames = [1, 2, 5, 9, 33, 100]
+    lens = [(T - 1) * S + W + int(rng.integers(0, S)) for T in frames]
+    offs, pos = [], int(rng.integers(0, 3))
+    for n in lens:
+        offs.append(pos)
+        pos += n + int(rng.integers(0, 4))
+    left = np.zeros(pos, np.int16)
+    right = np.zeros(pos, np.int16)
+    for i, (o_, n) in enumerate(zip(offs, lens)):
+        left[o_:o_ + n] = synth_utterance(n, 500 + 2 * i, sr=sr)
+        right[o_:o_ + n] = synth_utterance(n, 501 + 2 * i, sr=sr, f=277.0 + 31 * i)
+    mono = ((left.astype(np.int32) + right.astype(np.int32)) >> 1).astype(np.int16)
+    inter = np.empty(2 * pos, np.int16)
+    inter[0::2], inter[1::2] = left, right
+    kw = dict(W=W, S=S, nb=nb, sr=sr, nc=nc, dyn=dyn, l1=2, l2=2)
+    ms, cfg, w = make_pair(pkg, orc, max(lens) + 2000, channels=2, **kw)
+    assert ms.dominant_kernel_name() == "k_front512"
+    rows, total = ms.batch_plan(offs, lens)
+    got = ms.batch_run_host(inter)
+    assert total == sum(frames) and np.isfinite(got).all()
+    g = groups_of(dyn)
+    mm, _, _ = make_pair(pkg, orc, max(lens) + 2000, **kw)
+    mm.batch_plan(offs, lens)
+    assert_close(got, mm.batch_run_host(mono), "stereo in the kernel vs the host-side downmix", groups=g)
+    D = (2 + (2 if dyn == 2 else 0)) if dyn else 0
+    for i, (o_, n, T) in enumerate(zip(offs, lens, frames)):
+        if T <= 2 * D:
+            continue
+        want = orc.run_utterance(cfg, mono[o_:o_ + n], w, bug_compat=False)
+        assert_close(got[rows[i]:rows[i] + T], want, "utterance %d (%d frames)" % (i, T), groups=g)
+
+
 def test_c5_full_size_properties(pkg, orc):
     """BASELINE configs[4] at full size on one GPU: 200 stereo utterances x 10 s at 44.1 kHz (441 000 samples per channel)
     -> 199 600 frames x 120.  Every row written and finite, duplicate utterances give the same bits wherever they sit,
