@@ -326,7 +326,7 @@ void fill_front(const mfx_handle *h, FrontParams &p)
     p.mel32_row_stride = h->wplan32_ok ? h->wplan32.row_stride : 0;
     for (int i = 0; i < 8; ++i) p.mel32_L[i] = h->wplan32.L[i];
     p.dct_b = h->ceps > 0 ? h->d_dct_b.p : nullptr;
-    p.stuff = h->stuff256 ? 1 : 0;
+    p.stuff = h->stuff256 ? 512 / h->W2 : 0;
     p.dct_b4 = h->ceps > 0 ? h->d_dct_b4.p : nullptr;
     p.dct_b4s = (h->ceps > 0 && h->dct_split) ? h->d_dct_b4s.p : nullptr;
     p.dct_split = h->ceps > 0 ? h->dct_split : 0;
@@ -581,8 +581,8 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
         return MFX_ERR_CONFIG;
     }
     h->spec_pitch = ((h->W2 / 2 + 1) + 3) & ~3;
-    h->fast512 = front512_supported(h->W2, h->W, h->nb, h->cols, h->channels) && !(h->W2 == 256 && (h->cfg.engine & MFX_ENGINE_NO_STUFF256));
-    h->stuff256 = h->fast512 && h->W2 == 256;
+    h->fast512 = front512_supported(h->W2, h->W, h->nb, h->cols, h->channels) && !(h->W2 < 512 && (h->cfg.engine & MFX_ENGINE_NO_STUFF256));
+    h->stuff256 = h->fast512 && h->W2 < 512; // (256, 128 or 64 points: stuff factor 512 / W2)
     h->fast2048 = !(h->cfg.engine & MFX_ENGINE_NO_FRONT2048) && front2048_supported(h->W2, h->W, h->nb, h->cols, h->channels);
     h->fast1024 = !(h->cfg.engine & MFX_ENGINE_NO_FRONT1024) &&
                   front1024_supported(h->W2, h->W, h->nb, h->cols, h->channels, h->ceps);
@@ -592,7 +592,8 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
             h->num_cus = prop.multiProcessorCount;
         h->fuse_delta_enabled = (h->cfg.engine & MFX_ENGINE_FUSE_DELTA) != 0;
     }
-    h->nm16 = h->stuff256 ? (h->W + 15) / 16 : (h->W + 31) / 32; // rows of the frame that carry window taps
+    // rows of the frame that carry window taps: 32 samples per row, or 16 / 8 / 4 in the zero-stuffed forms
+    h->nm16 = h->stuff256 ? (h->W + h->W2 / 16 - 1) / (h->W2 / 16) : (h->W + 31) / 32;
 
     int rc = MFX_OK;
     auto bail = [&](int code) {
@@ -864,8 +865,9 @@ extern "C" int mfx_set_window(mfx_handle *h, const float *window)
         for (int l = 0; l < 16; ++l)
             for (int m = 0; m < 16; ++m) {
                 int n = l + 16 * m;
-                if (h->stuff256) { // zero-stuffed 256-point form: packed sample n = (x[n], 0)
-                    wp[2 * (l * 16 + m)] = padded[n] * fold;
+                if (h->stuff256) { // zero-stuffed forms: packed sample n = (x[n / step], 0) where step divides n, else (0, 0)
+                    const int step = 256 / h->W2;
+                    if (n % step == 0 && n / step < h->W2) wp[2 * (l * 16 + m)] = padded[n / step] * fold;
                     continue;
                 }
                 wp[2 * (l * 16 + m)] = padded[2 * n] * fold;

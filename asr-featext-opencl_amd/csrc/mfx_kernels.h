@@ -97,7 +97,7 @@ struct FrontParams {
     // DCT on the matrix pipe: B operands [dct_tiles][dct_ksteps][64] (build_dct_mfma_operands), read from L1 / L2
     const float *dct_b;
     const float *dct_b4;          // 4x4x1 form: [ceil(dct_len / 64)][dct_ksteps][64][4] (k_front2048, build_dct_mfma_operands4)
-    int32_t stuff;                // k_front512: 256-point transforms in the zero-stuffed form (one sample per lane and row)
+    int32_t stuff;                // k_front512: 0, or 512 / fft_size = 2, 4, 8: 256 / 128 / 64-point transforms in the zero-stuffed form
     const float *dct_b4s;         // k_front2048: the split form (build_dct_mfma_operands4_split) or nullptr
     int32_t dct_split;            // dct_split_mode(): 0 none, 1 pass A (<= 32 columns), 2 passes A + B (<= 40 columns)
     int32_t dct_tiles, dct_ksteps;

@@ -102,10 +102,10 @@ __device__ __forceinline__ void pcm_issue(PcmRegs<ALIGNED, NM> &r, __amdgpu_buff
 // The zero-stuffed form (256-point transforms on the 512-point core, k_front512<.., STUFF>): ONE sample per lane and row,
 // 16 samples per row; `voff` = byte offset of this lane's first sample
 template <int NM>
-__device__ __forceinline__ void pcm_issue_stuffed(PcmRegs<true, NM> &r, __amdgpu_buffer_rsrc_t rsrc, int voff)
+__device__ __forceinline__ void pcm_issue_stuffed(PcmRegs<true, NM> &r, __amdgpu_buffer_rsrc_t rsrc, int voff, int row_bytes)
 {
 #pragma unroll
-    for (int m = 0; m < NM; ++m) r.d[m] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, 32 * m, 0);
+    for (int m = 0; m < NM; ++m) r.d[m] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, row_bytes * m, 0);
 }
 
 // Dev-only in-kernel stamps (-DMFX_STAMPS): per-wave cycle sums per phase, written by lane 0 to
@@ -381,6 +381,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
+    const int stuff_sh = STUFF ? (p.stuff >= 8 ? 2 : p.stuff >= 4 ? 1 : 0) : 0; // log2(lanes per sample) of the zero-stuffed forms
     const int slot = lane >> 4, l = lane & 15, odd_slot = slot & 1;
 
     // ---- LDS carve: shared tables, then one 4-slot region per wave
@@ -570,8 +571,10 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
     };
     // byte offset of (frame f, sample pair l) relative to the chunk's descriptor base
     auto lane_off = [&](const ChunkCtx &x, int f) -> int {
-        if (CH2) return (f * p.shift + (STUFF ? l : 2 * l)) * 4;
-        if (STUFF) return (x.odd0 + f * p.shift + l) * 2; // (one sample per lane)
+        // (STUFF: p.stuff = 512 / W2 = 2, 4 or 8 -- a zero after every sample once, twice or three times over: every
+        // (p.stuff / 2)-th lane carries a sample, 16 / 8 / 4 samples per row; the other lanes meet zero window taps)
+        if (CH2) return (f * p.shift + (STUFF ? (l >> stuff_sh) : 2 * l)) * 4;
+        if (STUFF) return (x.odd0 + f * p.shift + (l >> stuff_sh)) * 2;
         const int s = x.odd0 + f * p.shift + 2 * l;
         return ALIGNED ? s * 2 : (s & ~1) * 2;
     };
@@ -598,7 +601,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
     auto issue = [&](__amdgpu_buffer_rsrc_t rsrc, int voff) {
         if constexpr (CH2 && STUFF) {
 #pragma unroll
-            for (int m = 0; m < NM; ++m) cur.d[m] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 64 * m, 0);
+            for (int m = 0; m < NM; ++m) cur.d[m] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (64 >> stuff_sh) * m, 0);
         } else if constexpr (CH2) {
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
@@ -607,7 +610,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
                 cur.d[2 * m + 1] = d[1];
             }
         } else if constexpr (STUFF) {
-            pcm_issue_stuffed<NM>(cur, rsrc, voff);
+            pcm_issue_stuffed<NM>(cur, rsrc, voff, 32 >> stuff_sh);
         } else {
             pcm_issue<ALIGNED, NM>(cur, rsrc, voff);
         }
@@ -742,10 +745,11 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
                     float *dst = p.spec + (out_row + f) * (int64_t)p.spec_pitch;
 #pragma unroll
                     for (int pp = 0; pp < 8; ++pp) {
-                        dst[l + 16 * pp] = mag_k[pp];
-                        if (!STUFF) dst[256 - l - 16 * pp] = mag_p[pp]; // (STUFF: a row holds bins 0 .. 128 of the 256-point transform)
+                        // (STUFF: a row holds bins 0 .. W2 / 2 of the short transform: 128, 64 or 32)
+                        if (!STUFF || l + 16 * pp <= (128 >> stuff_sh)) dst[l + 16 * pp] = mag_k[pp];
+                        if (!STUFF) dst[256 - l - 16 * pp] = mag_p[pp];
                     }
-                    if (l == 0) dst[128] = mag128;
+                    if (l == 0 && (!STUFF || stuff_sh == 0)) dst[128] = mag128;
                 }
             } else {
 #if defined(MFX_ABLATE) && MFX_ABLATE >= 1
@@ -2632,8 +2636,8 @@ hipError_t launch_front1024(const FrontParams &p, bool aligned, int nm16, hipStr
 
 bool front512_supported(int fft_size, int window_size, int num_banks, int cols, int channels)
 {
-    // (256 points: the zero-stuffed form of the same kernel, FrontParams::stuff)
-    return (fft_size == 512 || fft_size == 256) && window_size <= fft_size && window_size > 0 && channels <= 2 && num_banks >= 1 &&
+    // (256 / 128 / 64 points: the zero-stuffed forms of the same kernel, FrontParams::stuff = 512 / fft_size)
+    return (fft_size == 512 || fft_size == 256 || fft_size == 128 || fft_size == 64) && window_size <= fft_size && window_size > 0 && channels <= 2 && num_banks >= 1 &&
            num_banks <= 128 && cols <= 128;
 }
 

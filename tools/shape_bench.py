@@ -7,6 +7,8 @@ import __graft_entry__ as G
 pkg = G.load_package()
 import torch
 SHAPES = [  # name, sr, W, S, nb, nc, channels, seconds, n_utt
+    ("16 kHz fbank-80: 25/10 ms, 512-pt, 80 log mel energies, no deltas", 16000.0, 400, 160, 80, 0, 1, 10, 1000),
+    ("16 kHz fbank-40 + d + dd", 16000.0, 400, 160, 40, 0, 1, 10, 1000),
     ("8 kHz telephony, 25/10 ms, 256-pt, 23 mel, 13 MFCC + d + dd", 8000.0, 200, 80, 23, 13, 1, 10, 2000),
     ("11.025 kHz, 25/10 ms, 512-pt, 26 mel", 11025.0, 275, 110, 26, 13, 1, 10, 1000),
     ("16 kHz (C2)", 16000.0, 400, 160, 40, 13, 1, 10, 1000),
@@ -24,7 +26,8 @@ for name, sr, W, S, nb, nc, ch, sec, n_utt in SHAPES:
         continue
     n = int(sr * sec)
     n += n & 1
-    m = pkg.MfccHip(n + 1000, W, S, nb, sr, 64.0, sr / 2, nc, False, 22.0, 0, 2, 3, 3, True, channels=ch)
+    dyn = 0 if "no deltas" in name else 2
+    m = pkg.MfccHip(n + 1000, W, S, nb, sr, 64.0, sr / 2, nc, False, 22.0, 0, dyn, 3, 3, True, channels=ch)
     m.set_window(pkg.reference_window(W))
     rows, total = m.batch_plan(np.arange(n_utt) * n, np.full(n_utt, n))
     shape = (n_utt, n) if ch == 1 else (n_utt, n, 2)
