@@ -905,14 +905,18 @@ void host_copy(void *dst, const void *src, size_t bytes)
     for (unsigned t = 1; t < nt; ++t) th[t - 1].join();
 }
 
-bool is_pinned_host(const void *p)
+// page-locked host memory?  dev_ptr (optional): the address a kernel uses for it (the same address for hipHostMalloc memory;
+// registered memory reports its own)
+bool is_pinned_host(const void *p, void **dev_ptr = nullptr)
 {
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) {
         (void)hipGetLastError(); // plain pageable memory: not an error
         return false;
     }
-    return a.type == hipMemoryTypeHost;
+    if (a.type != hipMemoryTypeHost) return false;
+    if (dev_ptr) *dev_ptr = a.devicePointer ? a.devicePointer : const_cast<void *>(p);
+    return true;
 }
 
 constexpr size_t kCopyChunk = (size_t)4 << 20;
@@ -956,8 +960,9 @@ int download_rows(mfx_handle *h, float *dst, const float *d_src, size_t count)
     if (small_block(h, bytes)) {
         // small: a copy kernel writes the rows into page-locked memory (the caller's buffer if it is pinned, else the
         // staging buffer at the source's alignment), one stream wait, one memcpy
-        if (is_pinned_host(dst)) {
-            HIP_TRY(h, launch_copy_small(dst, d_src, bytes, h->stream));
+        void *dst_dev = nullptr;
+        if (is_pinned_host(dst, &dst_dev)) {
+            HIP_TRY(h, launch_copy_small(dst_dev, d_src, bytes, h->stream));
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             return MFX_OK;
         }

@@ -977,6 +977,24 @@ def test_small_block_copy_kernels_same_bits_as_dma(pkg, orc, norm, dyn):
             assert rc == 0
             got.append(t_out.numpy()[3:3 + n * width].reshape(n, width).copy())
     assert np.array_equal(np.concatenate(got), a)
+    # ... and into a caller buffer page-locked after the fact (hipHostRegister): the kernel uses its device address
+    reg = np.zeros(200 * width + 1024, np.float32)
+    rt = torch.cuda.cudart()
+    assert int(rt.cudaHostRegister(reg.ctypes.data, reg.nbytes, 0)) == 0
+    try:
+        m3, _, _ = make_pair(pkg, orc, 20000, **kw)
+        got, pos = [], 0
+        for bl in blocks + [0]:
+            n = m3.set_input(pcm[pos:pos + bl]) if bl else m3.flush()
+            pos += bl
+            if n > 0:
+                m3.apply()
+                rc = m3._L.mfx_get_output_data(m3._h, C.cast(reg.ctypes.data + 4, C.POINTER(C.c_float)), n)
+                assert rc == 0
+                got.append(reg[1:1 + n * width].reshape(n, width).copy())
+        assert np.array_equal(np.concatenate(got), a)
+    finally:
+        rt.cudaHostUnregister(reg.ctypes.data)
     if norm == 0:
         o = orc.OracleMfcc(cfg, w)
         rows, pos = [], 0
