@@ -2796,10 +2796,18 @@ hipError_t launch_front_generic(const FrontParams &p, bool fused, hipStream_t st
     int blocks = (p.n_chunks + 3) / 4;
     // persistent blocks, as many as are RESIDENT at once (registers: 6 per CU for the fused build; the LDS may allow fewer): a
     // grid of 8 per CU where 5 fit ran in two rounds -- 8 kHz / 256 points 2.46 ms per 2 M frames against 1.78 with 8 resident
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || per_cu < 1) {
-        (void)hipGetLastError();
-        per_cu = 4;
+    static thread_local const void *cached_fn = nullptr; // (one query per launch shape, not per launch)
+    static thread_local size_t cached_lds = 0;
+    static thread_local int cached_per_cu = 0;
+    int per_cu = cached_per_cu;
+    if (cached_fn != fn || cached_lds != lds) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            per_cu = 4;
+        }
+        cached_fn = fn;
+        cached_lds = lds;
+        cached_per_cu = per_cu;
     }
     const int cap = num_cus() * (per_cu > 8 ? 8 : per_cu);
     if (blocks > cap) blocks = cap;
@@ -2831,10 +2839,17 @@ hipError_t launch_melcep(const MelcepParams &p, hipStream_t stream)
     }
     int64_t blocks = ((p.n_rows + 3) / 4 + nw - 1) / nw;
     // persistent blocks: as many as are resident at once (registers allow 6 blocks of 4 waves; see launch_front_generic)
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_melcep, 64 * nw, lds) != hipSuccess || per_cu < 1) {
-        (void)hipGetLastError();
-        per_cu = (int)std::min<size_t>(4, (160 * 1024) / lds);
+    static thread_local int cached_nw = -1, cached_per_cu = 0; // (one query per launch shape, not per launch)
+    static thread_local size_t cached_lds = 0;
+    int per_cu = cached_per_cu;
+    if (cached_nw != nw || cached_lds != lds) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_melcep, 64 * nw, lds) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            per_cu = (int)std::min<size_t>(4, (160 * 1024) / lds);
+        }
+        cached_nw = nw;
+        cached_lds = lds;
+        cached_per_cu = per_cu;
     }
     if (per_cu > 8) per_cu = 8;
     const int cap = num_cus() * (per_cu < 1 ? 1 : per_cu);
