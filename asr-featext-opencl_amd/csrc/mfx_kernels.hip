@@ -1010,7 +1010,7 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
         // (MFX_DCT_QUARTERS: B operand of band 20 kb + j on lane (kb = lane >> 4, n = lane & 15); see k_front512)
         const int ln = i / kDctRowL, j = i - ln * kDctRowL, n = ln & 15;
         const int m = MFX_DCT_QUARTERS ? kDctStepsL * (ln >> 4) + j : 4 * j + (ln >> 4);
-        s_dct[i] = (m < p.num_banks && n < p.dct_len) ? p.dct[m * p.dct_len + n] : 0.f;
+        s_dct[i] = (p.dct && m < p.num_banks && n < p.dct_len) ? p.dct[m * p.dct_len + n] : 0.f;
     }
     for (int i = lane; i < 4 * kSlotL; i += 64) s_wave[i] = 0.f; // words read before they are written meet zero weights: finite
     __syncthreads();
@@ -1273,6 +1273,11 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
                 lm[fid] = MFX_LOG(fmaxf(acc, 1e-30f)); // (idle lanes: fid names a word nobody reads)
             }
             wave_sync();
+            if (!p.dct) {
+                // no DCT (ceps_len = 0: filterbank features, up to 80 log mel energies per frame): the frame's row as it is
+                if (live)
+                    for (int cc = l; cc < cols; cc += 16) dst[cc] = lm[cc];
+            } else
             // ---- DCT-II + lifter on the matrix pipe (see k_front512): frame `slot` in rows 4 slot .. 4 slot + 3
             {
 #if MFX_DCT_QUARTERS
@@ -2601,8 +2606,9 @@ size_t front1024_lds_bytes(const FrontParams &p)
 // (windows longer than 512 samples run on aligned frames only: launch_front1024 refuses the others)
 bool front1024_supported(int fft_size, int window_size, int num_banks, int cols, int channels, int ceps_len)
 {
+    // (with a DCT at most 16 columns -- the quartered matrix-pipe form; without one the log energies of up to 80 filters)
     return fft_size == 1024 && window_size > 0 && window_size <= 1024 && channels <= 1 && num_banks >= 1 &&
-           num_banks <= 4 * kDctStepsL && cols <= 16 && ceps_len > 0;
+           num_banks <= 4 * kDctStepsL && (ceps_len > 0 ? cols <= 16 : cols == num_banks);
 }
 
 namespace {

@@ -444,6 +444,9 @@ _F1024 = [
     (1024, 256, 80, 13, False, 0, 1.0),    # full-length window (32-row build)
     (600, 200, 40, 12, True, 1, 0.9),
     (1000, 333, 48, 13, False, 1, 1.0),    # long window on unaligned frames: stays on k_front_reg
+    (400, 160, 80, 0, False, 0, 1.0),      # filterbank features: 80 log mel energies per frame, no DCT
+    (1024, 256, 80, 0, False, 2, 1.0),     # ... full-length window, with deltas (240 columns)
+    (551, 220, 40, 0, False, 1, 1.05),     # ... 25 ms at 22.05 kHz, VTLN
 ]
 
 

@@ -9,6 +9,7 @@ import torch
 SHAPES = [  # name, sr, W, S, nb, nc, channels, seconds, n_utt
     ("16 kHz fbank-80: 25/10 ms, 512-pt, 80 log mel energies, no deltas", 16000.0, 400, 160, 80, 0, 1, 10, 1000),
     ("16 kHz fbank-40 + d + dd", 16000.0, 400, 160, 40, 0, 1, 10, 1000),
+    ("22.05 kHz fbank-80 (1024-pt, 25/10 ms), no deltas", 22050.0, 551, 220, 80, 0, 1, 10, 500),
     ("8 kHz telephony, 25/10 ms, 256-pt, 23 mel, 13 MFCC + d + dd", 8000.0, 200, 80, 23, 13, 1, 10, 2000),
     ("11.025 kHz, 25/10 ms, 512-pt, 26 mel", 11025.0, 275, 110, 26, 13, 1, 10, 1000),
     ("16 kHz (C2)", 16000.0, 400, 160, 40, 13, 1, 10, 1000),
