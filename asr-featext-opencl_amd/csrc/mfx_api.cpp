@@ -1726,7 +1726,7 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
     const bool fused1024 = allow_fused && h->fast1024 && h->fused_ok && (h->W <= 512 || h->batch_aligned); // (long windows: aligned frames only)
     // (up to 2048 points the fused form saves the spectrum's round trip through HBM -- 8 KB per frame at 2048
     // points; at 4096 points the tables + per-wave buffers no longer leave enough waves per CU)
-    // (2048 points, window <= 1280 samples: two frames per wave; mono off the aligned sample pairs -- odd shifts such as
+    // (2048 points, any window (18-, 20- and 32-row builds): two frames per wave; mono off the aligned sample pairs -- odd shifts such as
     // 441 samples = 10 ms at 44.1 kHz, odd offsets -- takes the any-alignment build: two words per pair, funnel-shifted)
     const bool fused2048 = allow_fused && h->fast2048 && h->wplan32_ok;
     const bool fusedgen = allow_fused && !fused512 && !fused1024 && !fused2048 && h->W2 <= 2048 && h->wplan_ok &&

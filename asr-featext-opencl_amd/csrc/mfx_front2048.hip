@@ -60,7 +60,11 @@ constexpr int kW2048 = MFX_W2048;        // waves per block; one block per CU (L
 constexpr int kPlane = 1040;      // floats per frame plane: 1024 transposition words / 1025 magnitudes + finite slack
 constexpr int kRows2048 = 18;     // rows of 32 sample pairs that can carry window taps: W <= 1152 (25 ms at 44.1 kHz)
 constexpr int kRows2048L = 20;    // the long-window build: W <= 1280 (25 ms at 48 kHz = 1200 taps)
-__host__ __device__ inline int rows2048(int window_size) { return window_size <= 64 * kRows2048 ? kRows2048 : kRows2048L; }
+constexpr int kRows2048F = 32;    // the full-window build: W <= 2048 (n_fft = win_length = 2048, the audio-analysis default)
+__host__ __device__ inline int rows2048(int window_size)
+{
+    return window_size <= 64 * kRows2048 ? kRows2048 : window_size <= 64 * kRows2048L ? kRows2048L : kRows2048F;
+}
 
 // cos / sin of 2 pi e / 32
 __host__ __device__ constexpr float c32(int e)
@@ -122,7 +126,7 @@ __host__ __device__ inline size_t front2048_table_floats(int rounds, int row_str
 
 // SPLIT: the DCT in its split form (p.dct_split != 0: <= 40 columns, bands a multiple of 32) -- a build of its own, so that
 // neither form carries the other's code and scalar registers
-// NR: rows of 32 sample pairs that carry window taps (18: W <= 1152; 20: W <= 1280) -- the zero rows fold away at compile time
+// NR: rows of 32 sample pairs that carry window taps (18: W <= 1152; 20: W <= 1280; 32: any window) -- the zero rows fold away at compile time
 // CH: 0 = mono, frames on aligned sample pairs (even offsets, even shift: one 32-bit word per pair); 1 = interleaved stereo (one
 // word per sample, any alignment); 2 = mono at ANY alignment (odd shifts -- 441 samples = 10 ms at 44.1 kHz -- or odd
 // offsets): the two aligned words that cover a pair are loaded and funnel-shifted by the frame's parity
@@ -132,7 +136,8 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
     constexpr int M = 1024;
     constexpr bool STEREO = CH == 1, ANY = CH == 2;
     // depth of the DCT's operand ring: what the build's registers allow without a spill
-    constexpr int kRingSplit = (ANY || (STEREO && NR > kRows2048)) ? 5 : 7, kRingTile = ANY ? 5 : 7;
+    constexpr int kRingSplit = ((STEREO || ANY) && NR >= kRows2048F) ? 3 : (ANY || (STEREO && NR > kRows2048)) ? 5 : 7;
+    constexpr int kRingTile = ((STEREO || ANY) && NR >= kRows2048F) ? 3 : ANY ? 5 : 7;
     constexpr int NWORD = (STEREO || ANY) ? 2 * NR : NR; // raw 32-bit words per lane and frame
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
@@ -543,7 +548,7 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
 
 bool front2048_supported(int fft_size, int window_size, int num_banks, int cols, int channels)
 {
-    return fft_size == 2048 && window_size > 0 && window_size <= 64 * kRows2048L && (channels == 1 || channels == 2) &&
+    return fft_size == 2048 && window_size > 0 && window_size <= 64 * kRows2048F && (channels == 1 || channels == 2) &&
            num_banks >= 1 && num_banks <= 256 && cols >= 1;
 }
 
@@ -578,7 +583,8 @@ hipError_t launch_front2048(const FrontParams &p, int num_cus, hipStream_t strea
     if (nw == 0) return hipErrorInvalidValue;
     const size_t lds = lds_bytes_2048(p, nw);
     const bool split = p.dct_split != 0 && p.dct_b4s != nullptr;
-    const bool wide = rows2048(p.window_size) == kRows2048L;
+    const int rows = rows2048(p.window_size);
+    const bool wide = rows == kRows2048L;
     int blocks = (p.n_chunks + nw - 1) / nw;
     if (blocks > num_cus) blocks = num_cus; // one block of up to 12 waves per CU
     if (blocks < 1) blocks = 1;
@@ -587,7 +593,11 @@ hipError_t launch_front2048(const FrontParams &p, int num_cus, hipStream_t strea
         if (lds > 64 * 1024) err = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err == hipSuccess) hipLaunchKernelGGL(kern, dim3(blocks), dim3(nw * 64), lds, stream, p);
     };
-    if (wide) {
+    if (rows == kRows2048F) {
+        if (ch == 1) { if (split) go(k_front2048<1, true, kRows2048F>); else go(k_front2048<1, false, kRows2048F>); }
+        else if (ch == 2) { if (split) go(k_front2048<2, true, kRows2048F>); else go(k_front2048<2, false, kRows2048F>); }
+        else { if (split) go(k_front2048<0, true, kRows2048F>); else go(k_front2048<0, false, kRows2048F>); }
+    } else if (wide) {
         if (ch == 1) { if (split) go(k_front2048<1, true, kRows2048L>); else go(k_front2048<1, false, kRows2048L>); }
         else if (ch == 2) { if (split) go(k_front2048<2, true, kRows2048L>); else go(k_front2048<2, false, kRows2048L>); }
         else { if (split) go(k_front2048<0, true, kRows2048L>); else go(k_front2048<0, false, kRows2048L>); }

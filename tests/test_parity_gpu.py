@@ -1577,6 +1577,9 @@ _F2048 = [  # W, S, sr, nb, nc, c0, dyn, channels, alpha
     (1200, 480, 48000.0, 128, 40, False, 2, 2, 1.0),     # 25 ms at 48 kHz: the 20-row build (W <= 1280), stereo, split DCT
     (1280, 480, 48000.0, 80, 13, False, 1, 1, 1.05),     # the longest window of the 20-row build, mono, one-tile DCT
     (1153, 577, 48000.0, 40, 20, True, 0, 2, 1.0),       # one tap past the 18-row build, odd shift, stereo
+    (2048, 512, 44100.0, 128, 40, False, 2, 1, 1.0),     # n_fft = win_length = 2048, hop 512 (the audio-analysis default): the 32-row build, mono
+    (2048, 441, 44100.0, 80, 0, False, 0, 2, 1.0),       # full window, stereo, 80 log mel energies
+    (1411, 441, 44100.0, 64, 20, True, 1, 1, 0.95),      # 32 ms at 44.1 kHz, mono at the odd shift (any-alignment build), VTLN
 ]
 
 

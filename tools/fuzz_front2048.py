@@ -11,7 +11,7 @@ worst, routed = 0.0, 0
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 for case in range(n_cases):
     ch = int(rng.integers(1, 3))
-    W = int(rng.integers(600, 1281))
+    W = int(rng.integers(600, 2049))
     S = int(rng.integers(max(8, W // 6), W + 1))
     even = ch == 1 and bool(rng.integers(0, 2))     # mono: half of the cases on aligned sample pairs, half at any alignment
     if even:

@@ -17,6 +17,7 @@ SHAPES = [  # name, sr, W, S, nb, nc, channels, seconds, n_utt
     ("32 kHz, 25/10 ms, 1024-pt, 64 mel", 32000.0, 800, 320, 64, 13, 1, 10, 400),
     ("44.1 kHz mono, 25/10 ms, 2048-pt, 128 mel, 40 MFCC", 44100.0, 1102, 441, 128, 40, 1, 10, 200),
     ("48 kHz mono, 25/10 ms, 2048-pt, 128 mel, 40 MFCC", 48000.0, 1200, 480, 128, 40, 1, 10, 200),
+    ("44.1 kHz mono, n_fft = win = 2048, hop 512, 128 mel, 40 MFCC", 44100.0, 2048, 512, 128, 40, 1, 10, 200),
     ("8 kHz STEREO (downmix in the kernel), 256-pt, 23 mel", 8000.0, 200, 80, 23, 13, 2, 10, 2000),
     ("16 kHz STEREO (downmix in the kernel), 512-pt, 40 mel", 16000.0, 400, 160, 40, 13, 2, 10, 1000),
     ("44.1 kHz STEREO (C5)", 44100.0, 1102, 441, 128, 40, 2, 10, 200),
