@@ -251,8 +251,11 @@ int refresh_mel(mfx_handle *h)
         std::vector<int32_t> L(h->wplan.L, h->wplan.L + 8);
         HIP_TRY(h, upload(h->d_mel64_L, L));
     }
-    {   // apply() runs k_melcep for every configuration: its tables + one wave's buffers must fit the CU's LDS (a few
-        // very wide filters on a long transform -- 8 filters over 1025 bins -- do not): refuse here, not at the first apply()
+    {   // apply() runs k_melcep for every configuration: its tables (one weight row per filter-carrying lane, mel64_rows)
+        // + one wave's buffers must fit the CU's LDS.  rows x row stride is at most ~4 x W2 floats for the reference's
+        // triangular banks, so every transform up to 4096 points fits whatever the filter count (4096 points, 48 kHz,
+        // 20 filters: 20 rows of 600 floats = 48 KB; refused until round 4, when all 64 lanes' rows were staged); 8192
+        // points and more with few, wide filters do not: refuse here, not at the first apply()
         MelcepParams probe;
         std::memset(&probe, 0, sizeof(probe));
         probe.num_banks = h->nb;
@@ -1219,6 +1222,17 @@ int prepare_sweep(mfx_handle *h, const float *alphas, int n)
         std::copy(plans[a].start.begin(), plans[a].start.end(), pst.begin() + (size_t)a * 64 * rounds);
         std::copy(plans[a].fid.begin(), plans[a].fid.end(), pfid.begin() + (size_t)a * 64 * rounds);
         std::copy(plans[a].L, plans[a].L + 8, pL.begin() + (size_t)a * 8);
+    }
+    {   // the sweep's common row stride may exceed the handle's own plan's: check k_melcep's LDS here (a CONFIG error
+        // at the call, not a launch failure later)
+        MelcepParams probe;
+        std::memset(&probe, 0, sizeof(probe));
+        probe.num_banks = h->nb;
+        probe.mel64_rounds = rounds;
+        probe.mel64_row_stride = rs;
+        probe.mag_floats = std::max(h->W2, (h->spec_pitch + 3) & ~3);
+        if (melcep_lds_bytes(probe, 1) > 160 * 1024)
+            return fail(h, MFX_ERR_CONFIG, "a warped mel filterbank of the sweep does not fit the kernels' LDS");
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(h->d_sweep_w.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));

@@ -250,11 +250,14 @@ __device__ __forceinline__ void dct_mfma4s(const float *arow, __amdgpu_buffer_rs
 // filter's bins in ascending order, one chain of multiply-adds (mfcccpu.cpp:206-217); weights from the lane's own
 // zero-padded row (16-byte reads, disjoint bank quads), magnitudes as 8-byte reads from even starts the host spread over
 // the banks.  mag must hold finite values up to the plan's last read.  The log energy of filter fid goes to lmf[fid]; idle
-// lanes park theirs in lmf[park].
+// lanes park theirs in lmf[park].  s_mw holds mel64_rows(nb) weight rows: filters are dealt to lanes 0, 1, ... of each
+// round, so lanes >= nb never carry one -- they walk the last staged row (same addresses: a broadcast) and park a finite value.
+__host__ __device__ __forceinline__ int mel64_rows(int num_banks) { return num_banks < 64 ? (num_banks > 0 ? num_banks : 1) : 64; }
+
 __device__ __forceinline__ void mel64_walk_log(const float *mag, float *lmf, int park, const float *s_mw, const int *s_mst,
-                                               const int *s_mfid, const int *Lr, int rounds, int RS, int lane)
+                                               const int *s_mfid, const int *Lr, int rounds, int RS, int lane, int w_rows)
 {
-    const float *wrow = s_mw + lane * RS;
+    const float *wrow = s_mw + (lane < w_rows ? lane : w_rows - 1) * RS;
     for (int r = 0; r < rounds; ++r) {
         const int st = s_mst[r * 64 + lane], fid = s_mfid[r * 64 + lane];
         const int L = Lr[r];

@@ -1370,8 +1370,9 @@ __global__ void __launch_bounds__(256, MFX_WAVE_MINW) k_front_wave(FrontParams p
     // shared tables (FUSED only: the 64-lane mel plan, MelWavePlan), then per wave: two complex buffers of M points and the
     // log mel energies of 4 frames waiting for the DCT (lm_fs4)
     const int RS = FUSED ? p.mel64_row_stride : 0, rounds = FUSED ? p.mel64_rounds : 0;
-    float *s_mw = smem;                                       // [64][RS]
-    int *s_mst = (int *)(s_mw + 64 * RS);                     // [rounds][64]
+    const int WR = mel64_rows(nb);                            // weight rows in LDS (lanes that carry a filter)
+    float *s_mw = smem;                                       // [WR][RS]
+    int *s_mst = (int *)(s_mw + WR * RS);                     // [rounds][64]
     int *s_mfid = s_mst + 64 * rounds;                        // [rounds][64]
     const int FS = FUSED ? lm_fs4(nb) : 0;
     float *s_wave = (float *)(s_mfid + 64 * rounds) + wave * (4 * M + 4 * FS);
@@ -1380,7 +1381,7 @@ __global__ void __launch_bounds__(256, MFX_WAVE_MINW) k_front_wave(FrontParams p
     float *lm = s_wave + 4 * M;                               // [4][FS]
     (void)dl;
     if (FUSED) {
-        for (int i = tid; i < 64 * RS; i += 256) s_mw[i] = p.mel64_w[i];
+        for (int i = tid; i < WR * RS; i += 256) s_mw[i] = p.mel64_w[i];
         for (int i = tid; i < 64 * rounds; i += 256) {
             s_mst[i] = p.mel64_start[i];
             s_mfid[i] = p.mel64_fid[i];
@@ -1485,7 +1486,7 @@ __global__ void __launch_bounds__(256, MFX_WAVE_MINW) k_front_wave(FrontParams p
             if (FUSED) {
                 // mel walk on the wave's 64 lanes + log (the magnitudes sit in the 2 M floats of the other buffer: the plan
                 // reads at most up to word W2 - 1, stale but finite beyond bin M); DCT once per 4 frames and at the chunk's end
-                mel64_walk_log(mag, lm + (f & 3) * FS, FS - 1, s_mw, s_mst, s_mfid, p.mel64_L, rounds, RS, lane);
+                mel64_walk_log(mag, lm + (f & 3) * FS, FS - 1, s_mw, s_mst, s_mfid, p.mel64_L, rounds, RS, lane, WR);
                 group_sync();
                 if ((f & 3) == 3 || f == nf - 1) {
                     const int g0 = f & ~3;
@@ -1622,8 +1623,9 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
     // FUSED: the mel walk's per-lane weight rows and plan (MelWavePlan), then per wave the complex buffer and the
     // log mel energies of 4 frames (the DCT runs on the matrix pipe once per 4 frames)
     const int RS = FUSED ? p.mel64_row_stride : 0, rounds = FUSED ? p.mel64_rounds : 0;
-    float *s_mw = (float *)(s_win + nwin);                     // [64][RS]
-    int *s_mst = (int *)(s_mw + 64 * RS);                      // [rounds][64]
+    const int WR = mel64_rows(nb);                             // weight rows in LDS (lanes that carry a filter)
+    float *s_mw = (float *)(s_win + nwin);                     // [WR][RS]
+    int *s_mst = (int *)(s_mw + WR * RS);                      // [rounds][64]
     int *s_mfid = s_mst + 64 * rounds;                         // [rounds][64]
     const int nbp = FUSED ? lm_stride(nb) : 0;
     float *s_wave = (float *)(s_mfid + 64 * rounds) + wave * (2 * MP + 4 * nbp);
@@ -1644,7 +1646,7 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
     }
     for (int i = tid; i <= M / 2; i += blockDim.x) s_cs[i] = ((const float2 *)p.twid_split)[i];
     if (FUSED) {
-        for (int i = tid; i < 64 * RS; i += blockDim.x) s_mw[i] = p.mel64_w[i];
+        for (int i = tid; i < WR * RS; i += blockDim.x) s_mw[i] = p.mel64_w[i];
         for (int i = tid; i < 64 * rounds; i += blockDim.x) {
             s_mst[i] = p.mel64_start[i];
             s_mfid[i] = p.mel64_fid[i];
@@ -1878,7 +1880,7 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
                 // disjoint bank quads), magnitudes as 8-byte reads from even starts the host spread over the banks.
                 {
                     float *lmf = lm + (f & 3) * nbp;
-                    const float *wrow = s_mw + lane * RS;
+                    const float *wrow = s_mw + (lane < WR ? lane : WR - 1) * RS;
                     auto one_round = [&](int r, int st, int fid) {
                         const int L = p.mel64_L[r];
                         const float *mg = mag + st;
@@ -2011,8 +2013,9 @@ __global__ void __launch_bounds__(256) k_melcep(MelcepParams p)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
     const int nb = p.num_banks, RS = p.mel64_row_stride, rounds = p.mel64_rounds;
     const int FS = lm_fs4(nb), MF = p.mag_floats;
-    float *s_mw = smem;                              // [64][RS]
-    int *s_mst = (int *)(s_mw + 64 * RS);            // [rounds][64]
+    const int WR = mel64_rows(nb);                   // weight rows in LDS (lanes that carry a filter)
+    float *s_mw = smem;                              // [WR][RS]
+    int *s_mst = (int *)(s_mw + WR * RS);            // [rounds][64]
     int *s_mfid = s_mst + 64 * rounds;               // [rounds][64]
     int *s_L = s_mfid + 64 * rounds;                 // [8]
     float *s_wave = (float *)(s_L + 8) + wave * (MF + 4 * FS);
@@ -2022,7 +2025,7 @@ __global__ void __launch_bounds__(256) k_melcep(MelcepParams p)
     const float *gw = p.mel64_w + (int64_t)table * 64 * RS;
     const int32_t *gst = p.mel64_start + (int64_t)table * 64 * rounds, *gfid = p.mel64_fid + (int64_t)table * 64 * rounds;
     float *feat = p.feat + (int64_t)table * p.feat_table_stride;
-    for (int i = tid; i < 64 * RS; i += blockDim.x) s_mw[i] = gw[i];
+    for (int i = tid; i < WR * RS; i += blockDim.x) s_mw[i] = gw[i];
     for (int i = tid; i < 64 * rounds; i += blockDim.x) {
         s_mst[i] = gst[i];
         s_mfid[i] = gfid[i];
@@ -2046,7 +2049,7 @@ __global__ void __launch_bounds__(256) k_melcep(MelcepParams p)
             // must be finite (0 x NaN is NaN)
             if (nbins + lane < 4 * q4) mag[nbins + lane] = 0.f;
             wave_sync();
-            mel64_walk_log(mag, lm + f * FS, FS - 1, s_mw, s_mst, s_mfid, s_L, rounds, RS, lane);
+            mel64_walk_log(mag, lm + f * FS, FS - 1, s_mw, s_mst, s_mfid, s_L, rounds, RS, lane, WR);
             wave_sync();
         }
         dct4_store<3>(lm, FS, dct_rsrc, dct_bytes, dct_ks, dct_tiles64, p.dct_b4 != nullptr, lane, p.cols, feat, (int64_t)p.feat_pitch,
@@ -2423,7 +2426,10 @@ __global__ void __launch_bounds__(kNormSegThreads) k_norm_seg(NormParams p)
     float *stats = p.stats + (int64_t)blockIdx.y * p.group_stats_stride + (int64_t)blockIdx.x * 2 * cols;
     const bool in_lds = n_out <= p.chunks;
     const int total = n_out * cols;
-    const uint32_t magic = 0xffffffffu / (uint32_t)cols + 1; // i / cols for i < 2^32 / cols (LDS-sized products)
+    // i / cols for i < 2^32 / cols (LDS-sized products).  cols == 1 would wrap the constant to 0: a one-column
+    // configuration (ceps_len 1 without c0, one filter without a DCT) takes the shift form instead
+    const uint32_t magic = cols > 1 ? 0xffffffffu / (uint32_t)cols + 1 : 0;
+    const auto row_of = [&](int i) -> int { return cols > 1 ? (int)__umulhi((uint32_t)i, magic) : i; };
     if (in_lds) { // 16 reads in flight per thread (a plain loop waits for every read before the next)
         const bool contig = p.pitch == cols;
         for (int i0 = tid; i0 < total; i0 += kNormSegThreads * 16) {
@@ -2431,7 +2437,7 @@ __global__ void __launch_bounds__(kNormSegThreads) k_norm_seg(NormParams p)
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int i = min(i0 + kNormSegThreads * k, total - 1); // (clamped, not predicated: no branch, all reads issued at once)
-                const int r = (int)__umulhi((uint32_t)i, magic), c = i - r * cols;
+                const int r = row_of(i), c = i - r * cols;
                 v[k] = base[contig ? (int64_t)i : (int64_t)r * p.pitch + c];
             }
 #pragma unroll
@@ -2481,7 +2487,7 @@ __global__ void __launch_bounds__(kNormSegThreads) k_norm_seg(NormParams p)
     __syncthreads();
     if (in_lds) {
         for (int i = tid; i < total; i += kNormSegThreads) {
-            const int r = (int)__umulhi((uint32_t)i, magic), cc = i - r * cols;
+            const int r = row_of(i), cc = i - r * cols;
             const float v = s_rows[i];
             base[(int64_t)r * p.pitch + cc] = p.norm_type == 1 ? v - s_st[cc] : (v - s_st[cc]) * s_st[256 + cc];
         }
@@ -2697,7 +2703,7 @@ size_t front_reg_lds_floats(const FrontParams &p, bool fused, int n_waves)
 {
     const size_t M = (size_t)p.fft_size >> 1;
     size_t f = 2 * M + 2 * (M / 2 + 2) + 2 * (size_t)reg_window_pairs(p.window_size, (int)M); // pass twiddles, split twiddles, window pairs
-    if (fused) f += (size_t)64 * p.mel64_row_stride + (size_t)128 * p.mel64_rounds; // lane weight rows, starts + filter ids
+    if (fused) f += (size_t)mel64_rows(p.num_banks) * p.mel64_row_stride + (size_t)128 * p.mel64_rounds; // lane weight rows, starts + filter ids
 #ifdef MFX_REG_PADDED
     const size_t MP = M + (M >> (p.fft_size == 1024 ? 3 : 4)); // padded buffer (pad_idx)
 #else
@@ -2777,7 +2783,7 @@ size_t front_wave_lds_bytes(const FrontParams &p, bool fused)
     }
     const int M = p.fft_size >> 1;
     size_t f = 0;
-    if (fused) f += (size_t)64 * p.mel64_row_stride + (size_t)128 * p.mel64_rounds; // lane weight rows, starts + filter ids
+    if (fused) f += (size_t)mel64_rows(p.num_banks) * p.mel64_row_stride + (size_t)128 * p.mel64_rounds; // lane weight rows, starts + filter ids
     f += 4 * ((size_t)4 * M + (fused ? 4 * (size_t)lm_fs4(p.num_banks) : 0));
     return f * sizeof(float);
 }
@@ -2826,7 +2832,7 @@ hipError_t launch_front_generic(const FrontParams &p, bool fused, hipStream_t st
 
 size_t melcep_lds_bytes(const MelcepParams &p, int n_waves)
 {
-    const size_t f = (size_t)64 * p.mel64_row_stride + (size_t)128 * p.mel64_rounds + 8 +
+    const size_t f = (size_t)mel64_rows(p.num_banks) * p.mel64_row_stride + (size_t)128 * p.mel64_rounds + 8 +
                      (size_t)n_waves * ((size_t)p.mag_floats + 4 * (size_t)lm_fs4(p.num_banks));
     return f * sizeof(float);
 }

@@ -317,18 +317,19 @@ def bench_batch(cfg, pcm2d, window=None, n_threads=1, reps=1, libpath=None):
 # ---------------------------------------------------------------------------------------------
 # the real reference stage objects (oracle/_ref/libref_stages.so)
 # ---------------------------------------------------------------------------------------------
-_ref = None
+_ref = {}
 
 
-def ref_available():
-    return os.path.exists(os.path.join(_HERE, "_ref", "libref_stages.so"))
+def ref_available(f32=False):
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_stages_f32.so" if f32 else "libref_stages.so"))
 
 
-def ref():
-    global _ref
-    if _ref is not None:
-        return _ref
-    p = os.path.join(_HERE, "_ref", "libref_stages.so")
+def ref(f32=False):
+    """f32 = the build whose unqualified libm names bind to the float overloads (oracle/Makefile ref_f32: the
+    reference's own toolchain's overload selection); default = the plain g++ build (C double functions, int abs)."""
+    if f32 in _ref:
+        return _ref[f32]
+    p = os.path.join(_HERE, "_ref", "libref_stages_f32.so" if f32 else "libref_stages.so")
     if not os.path.exists(p):
         raise RuntimeError("oracle/_ref not built (needs /root/reference): make -C oracle ref")
     R = C.CDLL(p)
@@ -355,27 +356,27 @@ def ref():
     R.ref_norm_new.restype, R.ref_norm_new.argtypes = vp, [C.c_int, C.c_int]
     R.ref_norm_free.argtypes = [vp]
     R.ref_norm_normalize.argtypes = [vp, fp, C.c_int, C.c_int]
-    _ref = R
+    _ref[f32] = R
     return R
 
 
 # ---------------------------------------------------------------------------------------------
 # the real MfccCpu member functions (oracle/_ref/libref_mfcccpu.so, see oracle/ref_mfcccpu_shim.cpp)
 # ---------------------------------------------------------------------------------------------
-_refm = None
+_refm = {}
 
 
-def refm_available():
-    return os.path.exists(os.path.join(_HERE, "_ref", "libref_mfcccpu.so"))
+def refm_available(f32=False):
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_mfcccpu_f32.so" if f32 else "libref_mfcccpu.so"))
 
 
-def refm():
-    global _refm
-    if _refm is not None:
-        return _refm
-    p = os.path.join(_HERE, "_ref", "libref_mfcccpu.so")
+def refm(f32=False):
+    """f32: see ref()."""
+    if f32 in _refm:
+        return _refm[f32]
+    p = os.path.join(_HERE, "_ref", "libref_mfcccpu_f32.so" if f32 else "libref_mfcccpu.so")
     if not os.path.exists(p):
-        raise RuntimeError("oracle/_ref/libref_mfcccpu.so not built (needs /root/reference): make -C oracle ref")
+        raise RuntimeError("oracle/_ref/%s not built (needs /root/reference): make -C oracle ref" % os.path.basename(p))
     R = C.CDLL(p)
     fp, ip, sp, vp = C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_short), C.c_void_p
     R.refm_new.restype = vp
@@ -401,7 +402,7 @@ def refm():
     R.refm_normalize.argtypes = [vp, C.c_int, C.c_int]
     R.refm_apply.argtypes = [vp]
     R.refm_get_output_data.argtypes = [vp, fp, C.c_int]
-    _refm = R
+    _refm[f32] = R
     return R
 
 
@@ -411,8 +412,8 @@ class RefMfccCpu:
     reference's compiled code; the transform at the FFTW call site (mfcccpu.cpp:187-190) is the double-precision DFT
     rounded to float that the oracle's fft_mode 0 also uses (orc_rfft_rows), written into the object's m_fft."""
 
-    def __init__(self, cfg, window=None):
-        self.R = refm()
+    def __init__(self, cfg, window=None, f32=False):
+        self.R = refm(f32)
         self.cfg = cfg
         self.h = self.R.refm_new(cfg.input_buffer_size, cfg.window_size, cfg.shift, cfg.num_banks, cfg.sample_rate,
                                  cfg.low_freq, cfg.high_freq, cfg.ceps_len, cfg.want_c0, cfg.lift_coef, cfg.norm,
@@ -536,9 +537,9 @@ class RefMfccCpu:
         return t
 
 
-def run_reference_utterance(cfg, pcm, window=None, alpha=1.0, block_samples=0):
+def run_reference_utterance(cfg, pcm, window=None, alpha=1.0, block_samples=0, f32=False):
     """ASR_OCL.cpp:149-301 over one utterance on the REAL MfccCpu -> [frames][width] (B1 and all)."""
-    m = RefMfccCpu(cfg, window)
+    m = RefMfccCpu(cfg, window, f32=f32)
     pcm = np.ascontiguousarray(pcm, dtype=np.int16)
     blk = m.input_buffer_size if block_samples <= 0 else min(block_samples, m.input_buffer_size)
     rows = []

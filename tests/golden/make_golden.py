@@ -16,6 +16,11 @@ Files
                            tests/refcases.py: rows, frames per call, mel tables, and filter()/dct() on synthetic spectra.
                            g++ binds the reference's unqualified libm calls to the double functions; the vectors are
                            therefore those of a g++ build of the reference (see oracle/mfcc_oracle.h, orc_set_libm_binding).
+  ref_mfcccpu_vectors_f32.npz  the same cases from oracle/_ref/libref_mfcccpu_f32.so: the same reference sources compiled with
+                           `-include math.h -include stdlib.h`, which makes the unqualified log/exp/atan/sin/cos/sqrt/abs
+                           calls pick the FLOAT overloads -- the selection the reference's own toolchain (MSVC) makes.  The
+                           checker's DEFAULT binding is bit-identical to these, MINMAX included; the HIP path is compared
+                           with them.
   c1_a0001_oracle.npz      features of BASELINE config C1 (a0001.wav, 26 mel, 13 MFCC + d + dd)
                            from this repo's oracle (oracle/mfcc_oracle.c).  NOT reference output:
                            mfcccpu.cpp needs libfftw3f and cannot be built here, and the reference
@@ -100,6 +105,16 @@ def ref_stage_vectors():
         R.ref_norm_free(nz)
         out["norm_in_%d" % nt], out["norm_out_%d" % nt] = x, a
         out["norm_in2_%d" % nt], out["norm_out2_%d" % nt] = x2, b
+        # the same NormalizerCPU built with the float overload binding of its unqualified abs() (normalizercpu.cpp:66;
+        # oracle/Makefile ref_f32): MINMAX without the int truncation of the plain g++ build
+        if O.ref_available(f32=True):
+            RF = O.ref(f32=True)
+            nz = RF.ref_norm_new(nt, dim)
+            a, b = x.copy(), x2.copy()
+            RF.ref_norm_normalize(nz, fp(a), n, 0)
+            RF.ref_norm_normalize(nz, fp(b), 11, 1)
+            RF.ref_norm_free(nz)
+            out["norm_out_%d_f32" % nt], out["norm_out2_%d_f32" % nt] = a, b
 
     # ---- ParamBase / MfccBase arithmetic
     rows = []
@@ -128,13 +143,16 @@ def c1_oracle():
     print("wrote c1_a0001_oracle.npz", multi.shape, single.shape, dflt.shape)
 
 
-def ref_mfcccpu_vectors():
+def ref_mfcccpu_vectors(f32=False):
+    """f32 = False: the plain g++ build (unqualified libm names -> C double functions, abs -> int abs(int));
+    f32 = True: oracle/_ref/libref_mfcccpu_f32.so, the same sources with the float overloads selected, as the
+    reference's own toolchain selects them (oracle/Makefile ref_f32) -> ref_mfcccpu_vectors_f32.npz."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import refcases as RC
     out = {}
     for name, c in RC.cases().items():
         pcm = RC.load_pcm(c["pcm"])
-        m = O.RefMfccCpu(RC.make_cfg(O, c), RC.case_window(O, c))
+        m = O.RefMfccCpu(RC.make_cfg(O, c), RC.case_window(O, c), f32=f32)
         rows, counts = RC.drive(m, pcm, c["alpha"])
         t = m.tables()
         out[name + "/rows"], out[name + "/counts"] = rows, counts
@@ -147,7 +165,7 @@ def ref_mfcccpu_vectors():
     for tag, W, nb, nc, sr, a in (("c2", 400, 40, 13, 16000.0, 1.0), ("c3", 1024, 80, 13, 16000.0, 0.9),
                                   ("c5", 1102, 128, 40, 44100.0, 1.1)):
         cfg = O.make_config(20 * W, window_size=W, shift=W // 2, num_banks=nb, sample_rate=sr, ceps_len=nc, dyn=O.DYN_NONE)
-        m = O.RefMfccCpu(cfg)
+        m = O.RefMfccCpu(cfg, f32=f32)
         W2, rows = m.fft_size, 6
         spec = (rng.standard_normal((rows, W2 // 2 + 1)) + 1j * rng.standard_normal((rows, W2 // 2 + 1))).astype(np.complex64)
         spec *= np.float32(50.0)
@@ -161,11 +179,16 @@ def ref_mfcccpu_vectors():
         out["stage_%s/spec" % tag], out["stage_%s/alpha" % tag] = spec, np.float32(a)
         out["stage_%s/mel" % tag], out["stage_%s/mfcc" % tag] = m.tap("mel", rows), m.tap("mfcc", rows)
         m.close()
-    np.savez_compressed(os.path.join(HERE, "ref_mfcccpu_vectors.npz"), **out)
-    print("wrote ref_mfcccpu_vectors.npz with", len(out), "arrays")
+    fn = "ref_mfcccpu_vectors_f32.npz" if f32 else "ref_mfcccpu_vectors.npz"
+    np.savez_compressed(os.path.join(HERE, fn), **out)
+    print("wrote", fn, "with", len(out), "arrays")
 
 
 if __name__ == "__main__":
+    if O.refm_available(f32=True):
+        ref_mfcccpu_vectors(f32=True)
+    else:
+        print("oracle/_ref/libref_mfcccpu_f32.so missing: ref_mfcccpu_vectors_f32.npz not regenerated")
     if O.refm_available():
         ref_mfcccpu_vectors()
     else:

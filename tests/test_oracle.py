@@ -105,6 +105,10 @@ def test_normalizer_matches_reference_vectors(orc, vec, nt):
     else:
         assert np.array_equal(x, want)
         assert np.array_equal(x2, want2)
+    # round 4: the same NormalizerCPU built with the float overload of its unqualified abs() (oracle/Makefile ref_f32, the
+    # selection the reference's own toolchain makes): the checker's default arithmetic is bit-identical, MINMAX included
+    assert np.array_equal(x, vec["norm_out_%d_f32" % nt])
+    assert np.array_equal(x2, vec["norm_out2_%d_f32" % nt])
 
 
 def test_base_arithmetic_matches_reference_vectors(orc, pkg, vec):

@@ -928,6 +928,56 @@ def test_one_launch_normaliser_same_bits_as_two_kernels(pkg, orc, norm, dyn, nad
         assert got[0].shape == got[1].shape and np.array_equal(got[0], got[1])
 
 
+@pytest.mark.parametrize("norm", [1, 2, 3])
+@pytest.mark.parametrize("dyn,nad", [(0, True), (2, True), (2, False)])
+@pytest.mark.parametrize("nb,nc", [(20, 1), (1, 0)])
+def test_one_column_configurations_normalise_correctly(pkg, orc, norm, dyn, nad, nb, nc):
+    """k_norm_seg's multiply-high division constant wrapped to 0 for cols == 1 (ceps_len 1 without c0; one filter
+    and no DCT) -- every element landed in row 0.  One-column configurations through the streaming interface (three-part
+    check against the oracle, normalizercpu.cpp:22-89) and the batch entry, one-launch and two-kernel normaliser: same bits."""
+    pcm = synth_utterance(30000, 61)
+    got = stream_normalised_check(pkg, orc, pcm, 12000, "one column nb=%d nc=%d norm=%d" % (nb, nc, norm), norm=norm,
+                                  dyn=dyn, nad=nad, nb=nb, nc=nc)
+    assert got.shape[1] == groups_of(dyn) and np.isfinite(got).all()
+    kw = dict(norm=norm, dyn=dyn, nad=nad, nb=nb, nc=nc)
+    m1, _, _ = make_pair(pkg, orc, 40000, **kw)
+    m2, _, _ = make_pair(pkg, orc, 40000, engine=pkg.mfcc.ENGINE_NORM_TWO_KERNELS, **kw)
+    lens = [16000, 4321, 9000]
+    offs = [0, 16000, 20322]
+    for m in (m1, m2):
+        m.batch_plan(offs, lens)
+    a, b = m1.batch_run_host(pcm), m2.batch_run_host(pcm)
+    assert a.shape[0] > 0 and np.isfinite(a).all() and np.array_equal(a, b)
+    batch_normalised_check(pkg, orc, pcm[:16000], "one column batch", norm=norm, dyn=dyn, nad=nad, nb=nb, nc=nc)
+
+
+@pytest.mark.parametrize("nb", [2, 3, 8, 20, 65])
+def test_few_wide_filters_on_a_4096_point_transform(pkg, orc, nb):
+    """with all 64 lanes' weight rows staged in LDS, 4096 points / 48 kHz / 20 filters (widest filter 594 bins,
+    64 x 600 floats = 153 KB + the magnitude row) was refused with MFX_ERR_CONFIG although the reference accepts any bank
+    count (mfcccpu.cpp:24-60).  Only the rows of lanes that carry a filter are staged now (mel64_rows): streaming
+    interface, an alpha sweep whose warped banks are wider than the handle's own, and the batch entry against the oracle."""
+    sr, W, S = 48000.0, 2400, 480
+    nc = min(nb - 1, 12)
+    pcm = synth_utterance(40000, 70 + nb, sr=sr)
+    m, cfg, w = make_pair(pkg, orc, 30000, W=W, S=S, nb=nb, sr=sr, nc=nc, dyn=2)
+    got = m.process_stream(pcm)
+    want = orc.run_utterance(cfg, pcm, w)
+    assert_close(got, want, "4096 points, %d filters (stream)" % nb, groups=3)
+    m.batch_plan([0], [pcm.size])
+    assert_close(m.batch_run_host(pcm), orc.run_utterance(cfg, pcm, w, bug_compat=False), "4096 points, %d filters (batch)" % nb,
+                 groups=3)
+    n = m.set_input(pcm[:30000])
+    alphas = [0.85, 1.0, 1.15]
+    m.apply_alphas(alphas)
+    o = orc.OracleMfcc(cfg, w)
+    assert o.set_input(pcm[:30000]) == n
+    for i, a in enumerate(alphas):
+        o.set_alpha(a)
+        o.apply()
+        assert_close(m.get_output_data_alpha(i, n), o.get_output_data(n), "4096 points, %d filters, alpha %.2f" % (nb, a), groups=3)
+
+
 @pytest.mark.parametrize("norm,dyn", [(0, 2), (2, 2), (0, 0)])
 def test_small_block_copy_kernels_same_bits_as_dma(pkg, orc, norm, dyn):
     """Streaming interface, blocks under 1 MB: the block goes to the device, the carried tail to the other carry buffer and
@@ -1398,12 +1448,18 @@ def test_batch_replan_and_alpha_change_between_runs(pkg, orc, fft):
 import refcases as RC  # noqa: E402
 
 _REFCASES = RC.cases()
-_REF_LIVE = os.path.exists(os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "libref_mfcccpu.so"))
+_REFDIR = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref")
+# Two builds of the reference (tests/test_ref_mfcccpu.py): "f32" = its unqualified libm names bound to the float overloads,
+# as its own toolchain binds them -- the checker's DEFAULT arithmetic is bit-identical to it; "gpp" = plain g++ (C double
+# functions, int abs), the checker under libm_double.
+_REF_BUILDS = {"f32": dict(file="ref_mfcccpu_vectors_f32.npz", libm_double=False, lib="libref_mfcccpu_f32.so"),
+               "gpp": dict(file="ref_mfcccpu_vectors.npz", libm_double=True, lib="libref_mfcccpu.so")}
+_REF_LIVE = all(os.path.exists(os.path.join(_REFDIR, v["lib"])) for v in _REF_BUILDS.values())
 
 
 @pytest.fixture(scope="module")
-def refvec():
-    return np.load(os.path.join(GOLDEN, "ref_mfcccpu_vectors.npz"))
+def refvecs():
+    return {b: np.load(os.path.join(GOLDEN, v["file"])) for b, v in _REF_BUILDS.items()}
 
 
 def _scale_floor(name):
@@ -1422,21 +1478,30 @@ def _hip_for_case(pkg, c, norm=None, bug_compat=True):
     return m
 
 
-@pytest.mark.parametrize("name", sorted(_REFCASES))
-def test_hip_streaming_vs_real_reference_vectors(pkg, orc, refvec, name):
+def _stream_cases():
+    """Every case against the float-bound build (MINMAX values included); every case but MINMAX against the plain g++
+    build as well -- that build divides by int(|extreme - mean|) (abs binds to int abs(int) under g++), an
+    artefact of a toolchain the reference was not written for, reproduced bit for bit by the checker's libm_double mode
+    on the CPU (tests/test_ref_mfcccpu.py) and not by the product."""
+    out = [(n, "f32") for n in sorted(_REFCASES)]
+    out += [(n, "gpp") for n in sorted(_REFCASES) if _REFCASES[n]["cfg"]["norm"] != RC.NORM_MINMAX]
+    return out
+
+
+@pytest.mark.parametrize("name,build", _stream_cases())
+def test_hip_streaming_vs_real_reference_vectors(pkg, orc, refvecs, name, build):
     """set_window -> {set_input -> set_alpha -> apply -> get_output_data}* -> flush -> ... (ASR_OCL.cpp:227-301) through the
     C ABI, block by block, against what the reference's own MfccCpu functions returned for the same calls.
     Un-normalised cases: every block at the north-star bar (1e-4 of scale, 1e-5 rel-L2) against the committed rows.
-    CMN / CVN: the three-part check of conftest.py, with the oracle under the g++ binding -- which this test first shows
-    to be bit-identical to the committed reference rows -- supplying the statistics.  MINMAX: the g++ build of the
-    reference truncates |min - mean| to an integer (SURVEY B4), a toolchain artefact the product does not reproduce;
-    its frame counts are checked here, its values against the oracle under the reference's own (MSVC) binding in
-    test_normalisation_*."""
+    CMN / CVN / MINMAX: the three-part check of conftest.py against the committed rows, with the checker under the build's
+    binding -- which this test first shows to be bit-identical to the committed reference rows, block by block --
+    supplying the statistics and the un-normalised twin."""
     from conftest import assert_normalised_close
     c = _REFCASES[name]
     k = c["cfg"]
+    dbl = _REF_BUILDS[build]["libm_double"]
     pcm, w = RC.load_pcm(c["pcm"]), RC.case_window(orc, c)
-    want_rows, want_counts = refvec[name + "/rows"], refvec[name + "/counts"]
+    want_rows, want_counts = refvecs[build][name + "/rows"], refvecs[build][name + "/counts"]
     g = groups_of(k["dyn"])
     m = _hip_for_case(pkg, c)
     m.set_window(w)
@@ -1445,8 +1510,8 @@ def test_hip_streaming_vs_real_reference_vectors(pkg, orc, refvec, name):
         m0 = _hip_for_case(pkg, c, norm=0)
         m0.set_window(w)
         case0 = dict(c, cfg=dict(k, norm=0))
-        o = orc.OracleMfcc(RC.make_cfg(orc, c), w, libm_double=True)
-        o0 = orc.OracleMfcc(RC.make_cfg(orc, case0), w, libm_double=True)
+        o = orc.OracleMfcc(RC.make_cfg(orc, c), w, libm_double=dbl)
+        o0 = orc.OracleMfcc(RC.make_cfg(orc, case0), w, libm_double=dbl)
     engines = [m] + ([m0, o, o0] if normed else [])
     blk, pos, row, counts = m.get_input_buffer_size(), 0, 0, []
     while True:
@@ -1462,12 +1527,12 @@ def test_hip_streaming_vs_real_reference_vectors(pkg, orc, refvec, name):
                 e.apply()
             y = m.get_output_data(n)
             want = want_rows[row:row + n]
-            what = "%s block %d" % (name, len(counts) - 1)
+            what = "%s [%s] block %d" % (name, build, len(counts) - 1)
             if not normed:
                 assert_close(y, want, what, groups=g, scale_floor=_scale_floor(name))
-            elif k["norm"] != RC.NORM_MINMAX:
+            else:
                 yo = o.get_output_data(n)
-                assert np.array_equal(yo, want, equal_nan=True), what + ": oracle (g++ binding) != committed reference rows"
+                assert np.array_equal(yo, want, equal_nan=True), what + ": checker != committed reference rows"
                 cols = y.shape[1] // g
                 st = m.debug_read(5).reshape(-1, 2, cols)
                 assert_normalised_close(y, want, m0.get_output_data(n), o0.get_output_data(n), st, o.norm_stats(), g,
@@ -1479,9 +1544,10 @@ def test_hip_streaming_vs_real_reference_vectors(pkg, orc, refvec, name):
     assert row == want_rows.shape[0]
 
 
+@pytest.mark.parametrize("build", sorted(_REF_BUILDS))
 @pytest.mark.parametrize("name", ["c1_multi", "c2_alpha088", "c2_alpha100", "c2_alpha112", "c3_alpha100", "c3_alpha112",
                                   "c3_streamed_dyn", "c5_alpha088", "c5_alpha100", "mel_only", "odd_geometry", "silence"])
-def test_hip_batch_entry_vs_real_reference_vectors(pkg, orc, refvec, name):
+def test_hip_batch_entry_vs_real_reference_vectors(pkg, orc, refvecs, name, build):
     """The batch entry (mfx_batch_plan + mfx_batch_run_host: the fused kernels the benchmark times) on the same inputs:
     whole-utterance rows against the reference's multi-block rows (block size does not change an un-normalised result,
     test_streaming_block_size_invariance; c3_alpha* are single blocks without deltas, where B1 cannot occur)."""
@@ -1492,28 +1558,38 @@ def test_hip_batch_entry_vs_real_reference_vectors(pkg, orc, refvec, name):
     m.set_alpha(c["alpha"])
     m.batch_plan([0], [pcm.size])
     got = m.batch_run_host(pcm)
-    assert_close(got, refvec[name + "/rows"], name + " batch entry", groups=groups_of(c["cfg"]["dyn"]),
-                 scale_floor=_scale_floor(name))
+    assert_close(got, refvecs[build][name + "/rows"], "%s [%s] batch entry" % (name, build),
+                 groups=groups_of(c["cfg"]["dyn"]), scale_floor=_scale_floor(name))
 
 
-@pytest.mark.skipif(not _REF_LIVE, reason="oracle/_ref/libref_mfcccpu.so did not travel")
-def test_hip_vs_live_real_reference_on_fresh_inputs(pkg, orc):
+@pytest.mark.skipif(not _REF_LIVE, reason="oracle/_ref/libref_mfcccpu{,_f32}.so did not travel")
+@pytest.mark.parametrize("build", sorted(_REF_BUILDS))
+def test_hip_vs_live_real_reference_on_fresh_inputs(pkg, orc, build):
     """The reference's compiled MfccCpu functions, loaded on the GPU box, against the HIP path on inputs no fixture holds:
-    C2-, C3- and C5-shaped utterances with new seeds and warps, streamed in uneven blocks."""
+    C2-, C3- and C5-shaped utterances with new seeds and warps, streamed in uneven blocks; a MINMAX configuration against
+    the float-bound build (block-level statistics: compared through the checker-free bound max|dy| <= 2e-4, the extreme's
+    own rounding: y = (x - mean) / max|x - mean| lies in [-1, 1])."""
+    f32 = build == "f32"
     for (tag, seed, alpha, ibs) in (("c2_alpha100", 501, 0.91, 11111), ("c3_streamed_dyn", 502, 1.09, 9500),
-                                    ("c5_alpha100", 503, 1.04, 17001), ("odd_geometry", 504, 0.97, 5003)):
+                                    ("c5_alpha100", 503, 1.04, 17001), ("odd_geometry", 504, 0.97, 5003),
+                                    ("dyn0_norm3_nad1", 505, 1.0, 5000)):
         base = _REFCASES[tag]
         k = base["cfg"]
+        if k["norm"] == RC.NORM_MINMAX and not f32:
+            continue
         c = dict(base, ibs=ibs, alpha=alpha, pcm=("synth", base["pcm"][1] + 7001, seed, k["sample_rate"]))
         pcm, w = RC.load_pcm(c["pcm"]), RC.case_window(orc, c)
-        r = orc.RefMfccCpu(RC.make_cfg(orc, c), w)
+        r = orc.RefMfccCpu(RC.make_cfg(orc, c), w, f32=f32)
         want, want_counts = RC.drive(r, pcm, alpha)
         r.close()
         m = _hip_for_case(pkg, c)
         m.set_window(w)
         got = m.process_stream(pcm, alpha=alpha)
         assert got.shape == want.shape, tag
-        assert_close(got, want, tag + " live reference", groups=groups_of(k["dyn"]))
+        if k["norm"] == RC.NORM_MINMAX:
+            assert np.abs(got - want).max() <= 2e-4, "%s live MINMAX: %g" % (tag, np.abs(got - want).max())
+        else:
+            assert_close(got, want, "%s live reference [%s]" % (tag, build), groups=groups_of(k["dyn"]))
 
 
 def test_sliced_batch_then_large_streaming_download_on_one_handle(pkg, orc):
