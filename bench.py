@@ -33,6 +33,18 @@ import __graft_entry__ as G  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP32_PEAK_TFLOPS = 157.3
+RCCL_PROBE_TIMEOUT_S = 60   # --collective rccl: a slow bring-up must not eat the driver's time limit
+
+# What the counters say limits each front-end kernel, and the committed profile the reading comes from (DESIGN.md
+# section 7).  roofline.bound stays the contract's nominal bound for this path ("hbm"); a kernel without a collected
+# profile gets no diagnosis (the label was hardcoded for every workload).
+BOUND_DIAGNOSED = {
+    "k_front512": ("valu_issue", "profiles/r03/v4_C2_pmc_summary.json: 182 VALU wave-instr per frame, ~0.8 of the issue slots"),
+    "k_front1024": ("valu_issue+lds_latency", "profiles/r03/v4_C3_pmc_summary.json: ~0.67 of the issue slots at 3 waves/SIMD, "
+                    "18 % of LDS cycles bank conflicts"),
+    "k_front2048": ("valu_issue+lds_latency", "profiles/r03/v4_C5_pmc_summary.json: ~0.65 of the issue slots at 3 waves/SIMD "
+                    "(LDS-capped occupancy)"),
+}
 
 WORKLOADS = {
     # name: (n_utt, utt_samples, sample_rate, W, S, fft, nb, nc, dyn)
@@ -279,7 +291,13 @@ def spawn_ranks(args):
     return 0
 
 
-def main():
+def resolve_backend(collective, environ):
+    """torch.distributed backend that carries the stopwatch's barrier for N > 1: "gloo" (default) or "nccl" (= RCCL, on
+    request: --collective rccl); MFX_BENCH_BACKEND overrides the flag (tests)."""
+    return environ.get("MFX_BENCH_BACKEND", {"rccl": "nccl"}.get(collective, collective))
+
+
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # The headline does not depend on these two: an untimed settle phase (--settle-ms of GPU work, reported as
@@ -292,13 +310,19 @@ def main():
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="strong: one job of the workload's n_utt_total utterances sharded round-robin over the ranks")
+    ap.add_argument("--collective", default="gloo", choices=["gloo", "rccl"],
+                    help="N > 1: what carries the barrier and the max-over-ranks (no collective is on the data path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--engine", type=int, default=0, help="mfx_config.engine bits (A/B of equivalent kernels; 0 = the library's choice)")
     ap.add_argument("--tail-split", type=int, default=0, help="mfx_config.tail_split (0 = default, -1 = off)")
     ap.add_argument("--overlap", action="store_true",
                     help="let the delta tail of a step overlap the next step's front end (mfx_batch_overlap); measured "
                          "neutral on MI355X -- the front end's waves fill the register file -- so off by default")
-    args = ap.parse_args()
+    return ap
+
+
+def main():
+    args = build_parser().parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
@@ -312,26 +336,29 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
-    # test knobs (rehearsing the N>1 path on a 1-GPU box): MFX_BENCH_DEVICE pins every rank to one
-    # device, MFX_BENCH_BACKEND=gloo replaces RCCL for the barrier / max-over-ranks
+    # test knob (rehearsing the N>1 path on a 1-GPU box): MFX_BENCH_DEVICE pins every rank to one device.
+    # --collective (MFX_BENCH_BACKEND overrides it): what carries the stopwatch's barrier and the max-over-ranks.  The data
+    # path has no collective (utterance shards are independent; north_star: "no RCCL needed"; the reference's own file
+    # queue has none either, ASR_OCL.cpp:340-368), so the default is gloo on CPU scalars beside torch.cuda.synchronize():
+    # an RCCL bring-up over 8 devices can take minutes of the driver's time limit and buys this benchmark nothing.
+    # `--collective rccl` uses device tensors over RCCL, probed with a 60 s limit and an agreed fallback to gloo.
     dev_index = int(os.environ.get("MFX_BENCH_DEVICE", local_rank))
-    backend = os.environ.get("MFX_BENCH_BACKEND", "nccl")
+    backend = resolve_backend(args.collective, os.environ)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
     group_dev = None   # the RCCL group (device tensors); None: the default gloo group carries the barriers
     if world > 1:
+        import datetime
         import torch.distributed as dist_mod
         dist = dist_mod
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
         if backend == "nccl":
-            # RCCL for the device-side barrier / reductions, gloo beside it: should RCCL fail to come up on some rank
-            # (no collective is on the data path -- it is only the stopwatch's barrier), all ranks agree over gloo to
-            # finish on CPU tensors, and the line says so (config.collective_backend)
-            import datetime
-            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
+            # RCCL for the device-side barrier / reductions, gloo beside it: should RCCL fail to come up on some rank,
+            # all ranks agree over gloo to finish on CPU tensors, and the line says so (config.collective_backend)
             bad = 0
             try:
-                group_dev = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300))
+                group_dev = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=RCCL_PROBE_TIMEOUT_S))
                 probe = torch.ones(1, device=device)
                 dist.all_reduce(probe, group=group_dev)
                 torch.cuda.synchronize()
@@ -345,11 +372,11 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             if int(flag.item()):
                 backend = "gloo"
-        else:
-            dist.init_process_group(backend=backend)
+        elif backend != "gloo":
+            raise SystemExit("bench.py: unknown collective backend %r" % backend)
 
-
-    def barrier():   # on the backend that came up (device tensor over RCCL, or CPU tensor over gloo)
+    def barrier():   # device work drained first, then the ranks meet (device tensor over RCCL, or CPU tensor over gloo)
+        torch.cuda.synchronize()
         t = torch.zeros(1, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, group=group_dev if backend == "nccl" else None)
         if backend == "nccl":
@@ -456,7 +483,7 @@ def main():
     # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, collected in their own rocprofv3 --pmc runs of
     # this same command and corrected as MI355X_MICROARCH.md prescribes): NOT measured in this run -- read from the
     # tracked profiles/traffic_latest.json, per workload and kernel, and labelled so
-    traffic, traffic_source = None, None
+    traffic, traffic_source, step_traffic = None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
@@ -465,6 +492,12 @@ def main():
             if ent.get("workload", args.workload) == args.workload and ent.get("kernel") == kname:
                 traffic = ent.get("hbm_bytes_per_launch")
                 traffic_source = "profiles/traffic_latest.json (%s)" % ent.get("source", "rocprofv3 --pmc passes")
+                # every kernel of the step (front end + delta (+ normaliser)): counter bytes per launch x launches per step
+                sk = ent.get("step_kernels")
+                if isinstance(sk, dict) and sk:
+                    step_traffic = {"bytes_per_step": sum(v["hbm_bytes_per_launch"] * v.get("launches_per_step", 1) for v in sk.values()),
+                                    "kernels": {k: v["hbm_bytes_per_launch"] for k, v in sk.items()},
+                                    "source": traffic_source}
         except Exception:
             traffic = None
     frames_per_launch = frames_rank / launches_per_step
@@ -476,7 +509,9 @@ def main():
         # What the counters say limits it is vector-instruction issue + dependent LDS round trips:
         # fully fused, the path has ~32 flop/B against a machine balance of ~20 flop/B, so 60 % of the HBM roofline
         # would need ~100 % of the FP32 vector peak.  Both fractions are reported.
-        "bound": "valu_issue", "bound_nominal": "hbm",
+        "bound": "hbm",
+        "bound_diagnosed": ({"label": BOUND_DIAGNOSED[kname][0], "source": BOUND_DIAGNOSED[kname][1]}
+                            if kname in BOUND_DIAGNOSED else None),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
         "kernel": kname, "kernel_avg_ms": avg_kernel_ms, "kernel_launches_per_step": launches_per_step,
@@ -493,7 +528,12 @@ def main():
         "whole_path": {"bytes_per_frame": path_bytes_per_frame,
                        "achieved": path_bytes_per_frame * frames_rank / (ms_per_step * 1e-3) / 1e9,
                        "frac": path_bytes_per_frame * frames_rank / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                       "achieved_tflops": path_tflops, "frac_fp32_peak": path_tflops / FP32_PEAK_TFLOPS},
+                       "achieved_tflops": path_tflops, "frac_fp32_peak": path_tflops / FP32_PEAK_TFLOPS,
+                       # counter bytes of ALL kernels of a step against the algorithmic bytes of the step
+                       "traffic": step_traffic["bytes_per_step"] if step_traffic else None,
+                       "traffic_kernels": step_traffic["kernels"] if step_traffic else None,
+                       "traffic_over_algorithmic": (step_traffic["bytes_per_step"] / (path_bytes_per_frame * frames_rank)
+                                                    if step_traffic else None)},
     }
 
     result = {

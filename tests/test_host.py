@@ -499,3 +499,17 @@ def test_cpp_driver_float_formatter_matches_printf():
         subprocess.check_call(["make", "-C", os.path.dirname(exe)])
     r = subprocess.run([exe, "--selftest-format", "300000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout, r.stderr)
+
+
+def test_bench_collective_default_is_gloo():
+    """bench.py --gpus N: the barrier / max-over-ranks ride on gloo unless RCCL is asked for (no collective is on the data
+    path; ASR_OCL.cpp:340-368 has none either), and the RCCL probe is bounded well below the driver's time limit."""
+    import bench
+    ap = bench.build_parser()
+    assert ap.parse_args([]).collective == "gloo"
+    assert bench.resolve_backend(ap.parse_args(["--gpus", "8"]).collective, {}) == "gloo"
+    assert bench.resolve_backend(ap.parse_args(["--collective", "rccl"]).collective, {}) == "nccl"
+    assert bench.resolve_backend("rccl", {"MFX_BENCH_BACKEND": "gloo"}) == "gloo"
+    assert bench.RCCL_PROBE_TIMEOUT_S <= 60
+    for name, (label, source) in bench.BOUND_DIAGNOSED.items():
+        assert os.path.exists(os.path.join(ROOT, source.split(":")[0])), source

@@ -23,7 +23,7 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
         if "mfx::" not in k: continue
-        short = next((n for n in ("k_front2048", "k_front512", "k_front1024", "k_front_reg", "k_front_wave", "k_delta16", "k_delta", "k_melcep", "k_norm_stats", "k_norm_finalize", "k_norm_apply") if n in k), k[:40])
+        short = next((n for n in ("k_front2048", "k_front512", "k_front1024", "k_front_reg", "k_front_wave", "k_delta16", "k_delta4", "k_delta", "k_melcep", "k_norm_seg", "k_norm_stats", "k_norm_finalize", "k_norm_apply") if n in k), k[:40])
         agg[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 json.dump(res, open(out + "/pmc_summary.json", "w"), indent=1, sort_keys=True)
@@ -42,6 +42,13 @@ if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
                "hbm_read_bytes_per_launch": 2 * 1024 * k["FETCH_SIZE"], "hbm_write_bytes_per_launch": 1024 * k["WRITE_SIZE"],
                "hbm_bytes_per_launch": 2 * 1024 * k["FETCH_SIZE"] + 1024 * k["WRITE_SIZE"],
                "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), WRITE_SIZE x1"}
+    # every kernel of the step (front end + delta (+ normaliser)): bench.py's roofline.whole_path.traffic
+    nfront = max(len(agg[kn]["FETCH_SIZE"]), 1)
+    traffic["step_kernels"] = {n: {"hbm_bytes_per_launch": 2 * 1024 * d["FETCH_SIZE"] + 1024 * d["WRITE_SIZE"],
+                                   "hbm_read_bytes_per_launch": 2 * 1024 * d["FETCH_SIZE"],
+                                   "hbm_write_bytes_per_launch": 1024 * d["WRITE_SIZE"],
+                                   "launches_per_step": len(agg[n]["FETCH_SIZE"]) / nfront}
+                               for n, d in res.items() if n.startswith("k_") and "FETCH_SIZE" in d and "WRITE_SIZE" in d}
     json.dump(traffic, open(out + "/traffic.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
 PY
