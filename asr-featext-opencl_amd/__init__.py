@@ -27,7 +27,9 @@ from .mfcc import (  # noqa: F401
     host_frame_count,
     host_mel_lane_plan,
     host_mel_table,
+    KERNEL_TABLE,
     library_path,
     load_library,
+    plan_kernel,
     reference_window,
 )

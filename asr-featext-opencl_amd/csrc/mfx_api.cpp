@@ -3,7 +3,7 @@
 // The streaming bookkeeping restates the reference's segmenter and apply() state machines
 // (segmentercpu.cpp:56-106 / segmenteropencl.cpp:120-175, mfcccpu.cpp:371-425 /
 // mfccopencl.cpp:495-549) on top of device buffers; all arithmetic on samples and features happens
-// in the HIP kernels of mfx_kernels.hip.  There is deliberately no CPU compute path in this file.
+// in the HIP kernels of mfx_front*.hip / mfx_tail.hip.  There is deliberately no CPU compute path in this file.
 #include "../../include/mfx.h"
 
 #include <hip/hip_runtime.h>
@@ -26,8 +26,15 @@ const char *kMsgBuffer = "Can't process data, buffer is too small";
 const char *kMsgWindow = "Can't process data, window count is too small";
 const char *kMsgProcessed = "Processed samples <= 0, this should never happen";
 const char *kMsgHigh = "Window count too high";
+const char *kMsgPlanning = "planning handle (mfx_plan_create): no device behind it";
 
 constexpr int kChunkFrames = 16; // frames per work item of the front-end kernels
+
+// A PLANNING handle (mfx_plan_create) runs mfx_create's own code -- the predicates, the host-built tables, the LDS sums that
+// decide which kernels a shape lands on -- with every device call left out: it can answer mfx_dominant_kernel_name and the
+// geometry accessors, and nothing else (no buffer exists; every other entry fails with MFX_ERR_DEVICE).  It is how the
+// shape -> kernel table of DESIGN.md section 5 is pinned by a test that needs no GPU.  It computes nothing.
+thread_local bool t_planning = false;
 
 template <class T>
 struct DevBuf {
@@ -37,7 +44,7 @@ struct DevBuf {
     {
         release();
         n = count;
-        if (count == 0) return hipSuccess;
+        if (count == 0 || t_planning) return hipSuccess;
         return hipMalloc((void **)&p, count * sizeof(T));
     }
     void release()
@@ -55,6 +62,7 @@ constexpr size_t kSmallBlock = (size_t)1 << 20; // below this a copy kernel repl
 struct mfx_handle {
     mfx_config cfg{};
     int device = 0;
+    bool planning = false; // mfx_plan_create: no device behind this handle (see t_planning)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
@@ -198,7 +206,7 @@ template <class T>
 hipError_t upload(DevBuf<T> &b, const std::vector<T> &v)
 {
     hipError_t e = b.alloc(v.size());
-    if (e != hipSuccess || v.empty()) return e;
+    if (e != hipSuccess || v.empty() || t_planning) return e;
     return hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
 }
 
@@ -214,7 +222,7 @@ int refresh_mel(mfx_handle *h)
     // every filter edge must address a computed bin
     for (int v : t.beg)
         if (v < 0 || v > h->W2 / 2) return fail(h, MFX_ERR_CONFIG, "mel filter edge outside [0, fft_size/2]");
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!t_planning) HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, upload(h->d_mel_w, t.weights));
     HIP_TRY(h, upload(h->d_mel_beg, t.beg));
     h->fused_ok = false;
@@ -448,6 +456,10 @@ extern "C" const char *mfx_last_error(const mfx_handle *h) { return h ? h->err.c
 extern "C" void mfx_destroy(mfx_handle *h)
 {
     if (!h) return;
+    if (h->planning) { // nothing was allocated
+        delete h;
+        return;
+    }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &ev : h->prof_events) {
@@ -531,7 +543,29 @@ extern "C" void mfx_destroy(mfx_handle *h)
     delete h;
 }
 
+namespace {
+int create_impl(const mfx_config *cfg, int hip_device, mfx_handle **out);
+}
+
 extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **out)
+{
+    t_planning = false;
+    return create_impl(cfg, hip_device, out);
+}
+
+/* A planning handle: see t_planning.  No device is touched; only mfx_dominant_kernel_name, the geometry accessors
+ * (mfx_get_output_data_width, mfx_get_input_buffer_size, mfx_estimated_window_count, mfx_max_frames_out, mfx_fft_size),
+ * mfx_last_error and mfx_destroy are meaningful on it. */
+extern "C" int mfx_plan_create(const mfx_config *cfg, mfx_handle **out)
+{
+    t_planning = true;
+    const int rc = create_impl(cfg, -1, out);
+    t_planning = false;
+    return rc;
+}
+
+namespace {
+int create_impl(const mfx_config *cfg, int hip_device, mfx_handle **out)
 {
     if (!cfg || !out) return MFX_ERR_ARG;
     *out = nullptr;
@@ -543,14 +577,17 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
     if (cfg->dyn != MFX_DYN_NONE && cfg->delta_l1 <= 0) return MFX_ERR_CONFIG;
     if (cfg->dyn == MFX_DYN_ACC && cfg->delta_l2 <= 0) return MFX_ERR_CONFIG;
 
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hip_device < 0 || hip_device >= ndev)
-        return MFX_ERR_DEVICE; // no CPU fallback by design
-    if (hipSetDevice(hip_device) != hipSuccess) return MFX_ERR_DEVICE;
+    if (!t_planning) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hip_device < 0 || hip_device >= ndev)
+            return MFX_ERR_DEVICE; // no CPU fallback by design
+        if (hipSetDevice(hip_device) != hipSuccess) return MFX_ERR_DEVICE;
+    }
 
     mfx_handle *h = new mfx_handle();
     h->cfg = *cfg;
     h->device = hip_device;
+    h->planning = t_planning;
     h->W = cfg->window_size;
     h->S = cfg->shift;
     h->nb = cfg->num_banks;
@@ -591,7 +628,7 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
                   front1024_supported(h->W2, h->W, h->nb, h->cols, h->channels, h->ceps);
     {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, hip_device) == hipSuccess && prop.multiProcessorCount > 0)
+        if (!t_planning && hipGetDeviceProperties(&prop, hip_device) == hipSuccess && prop.multiProcessorCount > 0)
             h->num_cus = prop.multiProcessorCount;
         h->fuse_delta_enabled = (h->cfg.engine & MFX_ENGINE_FUSE_DELTA) != 0;
     }
@@ -605,8 +642,10 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
         (void)msg;
         return code;
     };
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(MFX_ERR_DEVICE);
-    h->own_stream = true;
+    if (!t_planning) {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(MFX_ERR_DEVICE);
+        h->own_stream = true;
+    }
 
     // ---- constant tables
     {
@@ -690,7 +729,7 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
     const size_t carry_alloc = (h->carry_capacity + h->W2 + 8) & ~(size_t)1;
     for (int i = 0; i < 2; ++i) {
         if (h->d_carry[i].alloc(carry_alloc) != hipSuccess) return bail(MFX_ERR_DEVICE);
-        if (hipMemset(h->d_carry[i].p, 0, carry_alloc * sizeof(int16_t)) != hipSuccess) return bail(MFX_ERR_DEVICE);
+        if (!t_planning && hipMemset(h->d_carry[i].p, 0, carry_alloc * sizeof(int16_t)) != hipSuccess) return bail(MFX_ERR_DEVICE);
     }
     if (h->d_spec.alloc((size_t)h->cap_rows * h->spec_pitch) != hipSuccess) return bail(MFX_ERR_DEVICE);
     if (h->d_src.alloc((size_t)h->cap_rows * h->cols) != hipSuccess) return bail(MFX_ERR_DEVICE);
@@ -700,7 +739,7 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
         const size_t need = norm_partial_doubles(1, h->cap_rows, h->cols);
         if (need > 0 && h->d_norm_partial.alloc(need) != hipSuccess) return bail(MFX_ERR_DEVICE);
     }
-    if (hipMemset(h->d_stats_stream.p, 0, (size_t)3 * 2 * h->cols * sizeof(float)) != hipSuccess)
+    if (!t_planning && hipMemset(h->d_stats_stream.p, 0, (size_t)3 * 2 * h->cols * sizeof(float)) != hipSuccess)
         return bail(MFX_ERR_DEVICE);
     {
         // work items of a streaming block: 16 frames, or 4 where a whole block is only a few thousand frames (one 10-s
@@ -720,12 +759,13 @@ extern "C" int mfx_create(const mfx_config *cfg, int hip_device, mfx_handle **ou
     h->host_tail = !(h->cfg.engine & MFX_ENGINE_DMA_SMALL_BLOCKS) && (h->carry_capacity + 8) * sizeof(int16_t) < kSmallBlock;
     // (+ 16 bytes: small blocks are staged at the destination's alignment; host_tail: tail + block, up to the carry capacity)
     h->h_stage_n = (h->host_tail ? h->carry_capacity : (size_t)h->input_buffer_size) + 8;
-    if (hipHostMalloc((void **)&h->h_stage, h->h_stage_n * sizeof(int16_t), hipHostMallocDefault) != hipSuccess)
+    if (!t_planning && hipHostMalloc((void **)&h->h_stage, h->h_stage_n * sizeof(int16_t), hipHostMallocDefault) != hipSuccess)
         return bail(MFX_ERR_DEVICE);
 
     *out = h;
     return MFX_OK;
 }
+} // namespace
 
 // ------------------------------------------------------------------------------------------------
 // simple accessors
@@ -750,6 +790,7 @@ extern "C" int mfx_set_alpha(mfx_handle *h, float alpha)
 extern "C" int mfx_set_stream(mfx_handle *h, void *hip_stream)
 {
     if (!h) return MFX_ERR_ARG;
+    if (h->planning) return fail(h, MFX_ERR_DEVICE, kMsgPlanning);
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->stream) HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -761,6 +802,7 @@ extern "C" int mfx_set_stream(mfx_handle *h, void *hip_stream)
 extern "C" int mfx_synchronize(mfx_handle *h)
 {
     if (!h) return MFX_ERR_ARG;
+    if (h->planning) return fail(h, MFX_ERR_DEVICE, kMsgPlanning);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->stream2) HIP_TRY(h, hipStreamSynchronize(h->stream2));
     h->tail_pending[0] = h->tail_pending[1] = false;
@@ -778,6 +820,7 @@ extern "C" int mfx_synchronize(mfx_handle *h)
 extern "C" int mfx_profile_enable(mfx_handle *h, int enable)
 {
     if (!h) return MFX_ERR_ARG;
+    if (h->planning) return fail(h, MFX_ERR_DEVICE, kMsgPlanning);
     int rc = prof_collect(h);
     h->prof_on = enable != 0;
     return rc;
@@ -786,6 +829,7 @@ extern "C" int mfx_profile_enable(mfx_handle *h, int enable)
 extern "C" int mfx_profile_read(mfx_handle *h, int32_t *launches, double *kernel_ms, int reset)
 {
     if (!h) return MFX_ERR_ARG;
+    if (h->planning) return fail(h, MFX_ERR_DEVICE, kMsgPlanning);
     int rc = prof_collect(h);
     if (rc != MFX_OK) return rc;
     if (launches) *launches = h->prof_launches;
@@ -797,11 +841,51 @@ extern "C" int mfx_profile_read(mfx_handle *h, int32_t *launches, double *kernel
     return MFX_OK;
 }
 
+namespace {
+// Which front-end kernel the BATCH entries run for this handle -- the ONE place that decides it (run_batch_range launches what
+// this returns; mfx_dominant_kernel_name prints it; DESIGN.md section 5 tabulates it; tests/test_host.py pins the table
+// through planning handles).  Order of preference: the three register kernels (4 frames per wave at 512 points and the
+// short-window 1024-point case, 2 frames per wave at 2048 points), then the fused one-wave-per-frame kernels while their LDS
+// fits (<= 2048 points), then spectrum through an HBM slab + k_melcep.
+enum FrontKind { kFront512, kFront1024, kFront2048, kFrontGenFused, kSpec512, kSpecGen };
+FrontKind choose_front(const mfx_handle *h)
+{
+    const bool allow_fused = !(h->cfg.engine & MFX_ENGINE_STREAM_KERNELS); // (else: the streaming interface's kernels)
+    if (allow_fused && h->fast512 && h->fused_ok) return kFront512;
+    // (k_front1024, windows longer than 512 samples: aligned frames only)
+    if (allow_fused && h->fast1024 && h->fused_ok && (h->W <= 512 || h->batch_aligned)) return kFront1024;
+    // (2048 points, any window: stereo, mono on aligned sample pairs, mono at any alignment -- three builds)
+    if (allow_fused && h->fast2048 && h->wplan32_ok) return kFront2048;
+    // (up to 2048 points the fused form saves the spectrum's round trip through HBM -- 8 KB per frame at 2048 points; at 4096
+    // points the tables + per-wave buffers no longer leave enough waves per CU)
+    if (allow_fused && h->W2 <= 2048 && h->wplan_ok) {
+        FrontParams probe;
+        fill_front(h, probe);
+        if (front_wave_lds_bytes(probe, true) <= 160 * 1024) return kFrontGenFused;
+    }
+    return h->fast512 ? kSpec512 : kSpecGen;
+}
+} // namespace
+
 extern "C" const char *mfx_dominant_kernel_name(const mfx_handle *h)
 {
     if (!h) return "";
-    if (h->fast2048 && h->wplan32_ok) return "k_front2048";
-    return h->fast512 ? "k_front512" : (h->fast1024 && h->fused_ok && (h->W <= 512 || h->batch_aligned)) ? "k_front1024" : h->W2 >= 1024 ? "k_front_reg" : "k_front_wave"; // names as rocprofv3 prints them
+    switch (choose_front(h)) { // names as rocprofv3 prints them
+    case kFront512:
+    case kSpec512: return "k_front512";
+    case kFront1024: return "k_front1024";
+    case kFront2048: return "k_front2048";
+    default: return h->W2 >= 1024 ? "k_front_reg" : "k_front_wave";
+    }
+}
+
+/* planning handles only: frames of the batch on aligned sample pairs (even offsets and shift) or not -- what mfx_batch_plan
+ * derives from the caller's offsets on a real handle */
+extern "C" int mfx_plan_set_aligned(mfx_handle *h, int aligned)
+{
+    if (!h || !h->planning) return MFX_ERR_ARG;
+    h->batch_aligned = aligned != 0;
+    return MFX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -811,6 +895,7 @@ extern "C" const char *mfx_dominant_kernel_name(const mfx_handle *h)
 extern "C" int mfx_set_window(mfx_handle *h, const float *window)
 {
     if (!h) return MFX_ERR_ARG;
+    if (h->planning) return fail(h, MFX_ERR_DEVICE, kMsgPlanning);
     if (!window) return fail(h, MFX_ERR_ARG, "invalid argument");
     HIP_TRY(h, hipSetDevice(h->device));
     std::vector<float> padded((size_t)h->W2, 0.f);
@@ -1058,6 +1143,7 @@ int carry_tail(mfx_handle *h, int total_samples)
 extern "C" int mfx_set_input(mfx_handle *h, const int16_t *pcm, int32_t samples, int32_t *frames_out)
 {
     if (!h) return MFX_ERR_ARG;
+    if (h->planning) return fail(h, MFX_ERR_DEVICE, kMsgPlanning);
     if (!pcm || !frames_out || samples < 0) return fail(h, MFX_ERR_ARG, "invalid argument");
     *frames_out = 0;
     if (!h->have_window) return fail(h, MFX_ERR_STATE, "set_window has not been called");
@@ -1151,6 +1237,7 @@ extern "C" int mfx_set_input(mfx_handle *h, const int16_t *pcm, int32_t samples,
 extern "C" int mfx_flush(mfx_handle *h, int32_t *frames_out)
 {
     if (!h) return MFX_ERR_ARG;
+    if (h->planning) return fail(h, MFX_ERR_DEVICE, kMsgPlanning);
     if (!frames_out) return fail(h, MFX_ERR_ARG, "invalid argument");
     *frames_out = 0;
     if (h->last_block) return MFX_OK; // nothing to flush (mfcccpu.cpp:350-351)
@@ -1399,12 +1486,14 @@ int apply_impl(mfx_handle *h, const float *alphas, int n_alpha)
 extern "C" int mfx_apply(mfx_handle *h)
 {
     if (!h) return MFX_ERR_ARG;
+    if (h->planning) return fail(h, MFX_ERR_DEVICE, kMsgPlanning);
     return apply_impl(h, nullptr, 0);
 }
 
 extern "C" int mfx_apply_alphas(mfx_handle *h, const float *alphas, int32_t n_alpha)
 {
     if (!h) return MFX_ERR_ARG;
+    if (h->planning) return fail(h, MFX_ERR_DEVICE, kMsgPlanning);
     if (!alphas || n_alpha < 1 || n_alpha > 4096) return fail(h, MFX_ERR_ARG, "invalid argument");
     for (int a = 0; a < n_alpha; ++a)
         if (!(alphas[a] > 0.f)) return fail(h, MFX_ERR_ARG, "alpha must be positive");
@@ -1414,6 +1503,7 @@ extern "C" int mfx_apply_alphas(mfx_handle *h, const float *alphas, int32_t n_al
 extern "C" int mfx_get_output_data_alpha(mfx_handle *h, int32_t alpha_index, float *data_out, int32_t frames)
 {
     if (!h) return MFX_ERR_ARG;
+    if (h->planning) return fail(h, MFX_ERR_DEVICE, kMsgPlanning);
     if ((!data_out && frames > 0) || frames < 0) return fail(h, MFX_ERR_ARG, "invalid argument");
     if (alpha_index < 0 || alpha_index >= h->sweep_n) return fail(h, MFX_ERR_ARG, "alpha index outside the last sweep");
     if (frames > h->cap_rows) return fail(h, MFX_ERR_WINDOW_HIGH, kMsgHigh);
@@ -1425,6 +1515,7 @@ extern "C" int mfx_get_output_data_alpha(mfx_handle *h, int32_t alpha_index, flo
 extern "C" int mfx_get_output_data(mfx_handle *h, float *data_out, int32_t frames)
 {
     if (!h) return MFX_ERR_ARG;
+    if (h->planning) return fail(h, MFX_ERR_DEVICE, kMsgPlanning);
     if ((!data_out && frames > 0) || frames < 0) return fail(h, MFX_ERR_ARG, "invalid argument");
     if (frames > h->cap_rows) return fail(h, MFX_ERR_WINDOW_HIGH, kMsgHigh);
     if (frames == 0) return MFX_OK;
@@ -1588,6 +1679,7 @@ extern "C" int mfx_batch_plan(mfx_handle *h, int32_t n_utt, const int64_t *offse
                               int64_t *out_rows, int64_t *total_rows)
 {
     if (!h) return MFX_ERR_ARG;
+    if (h->planning) return fail(h, MFX_ERR_DEVICE, kMsgPlanning);
     if (n_utt < 0 || (n_utt > 0 && (!offsets || !lengths))) return fail(h, MFX_ERR_ARG, "invalid argument");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1703,6 +1795,7 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
 extern "C" int mfx_batch_run_device(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_total, float *d_out)
 {
     if (!h) return MFX_ERR_ARG;
+    if (h->planning) return fail(h, MFX_ERR_DEVICE, kMsgPlanning);
     return batch_run_range(h, d_pcm, pcm_samples_total, d_out, 0, h->n_utt);
 }
 
@@ -1735,16 +1828,9 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
 
     // Which front end: the 512-point register kernel, else the fused wave-per-frame kernel when its
     // LDS fits, else spectrum through an HBM slab + melcep.
-    const bool allow_fused = !(h->cfg.engine & MFX_ENGINE_STREAM_KERNELS); // (else: the streaming interface's kernels)
-    const bool fused512 = allow_fused && h->fast512 && h->fused_ok;
-    const bool fused1024 = allow_fused && h->fast1024 && h->fused_ok && (h->W <= 512 || h->batch_aligned); // (long windows: aligned frames only)
-    // (up to 2048 points the fused form saves the spectrum's round trip through HBM -- 8 KB per frame at 2048
-    // points; at 4096 points the tables + per-wave buffers no longer leave enough waves per CU)
-    // (2048 points, any window (18-, 20- and 32-row builds): two frames per wave; mono off the aligned sample pairs -- odd shifts such as
-    // 441 samples = 10 ms at 44.1 kHz, odd offsets -- takes the any-alignment build: two words per pair, funnel-shifted)
-    const bool fused2048 = allow_fused && h->fast2048 && h->wplan32_ok;
-    const bool fusedgen = allow_fused && !fused512 && !fused1024 && !fused2048 && h->W2 <= 2048 && h->wplan_ok &&
-                          front_wave_lds_bytes(p, true) <= 160 * 1024;
+    const FrontKind kind = choose_front(h);
+    const bool fused512 = kind == kFront512, fused1024 = kind == kFront1024, fused2048 = kind == kFront2048,
+               fusedgen = kind == kFrontGenFused;
     // With deltas on, the front end writes its statics as compact 64-byte rows into a scratch buffer
     // and the delta kernel emits whole [static | d | dd] rows: every HBM write is then a full line
     // (13-float row pieces at a 156-byte pitch cost 1.5x their size in 32-byte sectors).
@@ -1899,6 +1985,7 @@ extern "C" void mfx_free_pinned(void *p)
 extern "C" int mfx_batch_overlap(mfx_handle *h, int enable)
 {
     if (!h) return MFX_ERR_ARG;
+    if (h->planning) return fail(h, MFX_ERR_DEVICE, kMsgPlanning);
     HIP_TRY(h, hipSetDevice(h->device));
     int rc = mfx_synchronize(h);
     if (rc != MFX_OK) return rc;
@@ -1920,6 +2007,7 @@ extern "C" int mfx_batch_overlap(mfx_handle *h, int enable)
 extern "C" int mfx_batch_run_host(mfx_handle *h, const int16_t *pcm, int64_t pcm_samples_total, float *out)
 {
     if (!h) return MFX_ERR_ARG;
+    if (h->planning) return fail(h, MFX_ERR_DEVICE, kMsgPlanning);
     if (!pcm || !out || pcm_samples_total <= 0) return fail(h, MFX_ERR_ARG, "invalid argument");
     HIP_TRY(h, hipSetDevice(h->device));
     // device-side staging of the host buffers, kept by the handle and grown on demand
@@ -2006,6 +2094,7 @@ extern "C" int mfx_batch_run_host(mfx_handle *h, const int16_t *pcm, int64_t pcm
 extern "C" int64_t mfx_debug_read(mfx_handle *h, int kind, void *dst, int64_t dst_bytes)
 {
     if (!h) return MFX_ERR_ARG;
+    if (h->planning) return fail(h, MFX_ERR_DEVICE, kMsgPlanning);
     if (!dst) return fail(h, MFX_ERR_ARG, "invalid argument");
     if (hipSetDevice(h->device) != hipSuccess) return MFX_ERR_DEVICE;
     const void *src = nullptr;

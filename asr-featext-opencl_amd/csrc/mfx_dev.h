@@ -1,4 +1,4 @@
-// mfx_dev.h -- device helpers shared by the gfx950 kernel translation units (mfx_kernels.hip, mfx_front2048.hip):
+// mfx_dev.h -- device helpers shared by the gfx950 kernel translation units (mfx_front512.hip, mfx_front_generic.hip, mfx_front2048.hip, mfx_tail.hip):
 // wave-level LDS ordering, LDS reads the optimiser must keep whole, the register FFT butterflies, the fast log.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1,4 +1,4 @@
-// mfx_kernels.h -- launch interface of the gfx950 kernels (implemented in mfx_kernels.hip).
+// mfx_kernels.h -- launch interface of the gfx950 kernels (implemented in mfx_front512.hip, mfx_front_generic.hip, mfx_front2048.hip, mfx_tail.hip: one translation unit per kernel family).
 //
 // Kernel inventory and the reference stage each one replaces:
 //   spectrum512 / fused512   segmenter.cl kernelSegmentWindow + AppleFFT fft0 + mfcc.cl kernelTranspose

@@ -62,7 +62,7 @@ EXPORTED_SYMBOLS = (
     "mfx_batch_frames", "mfx_batch_plan", "mfx_batch_run_device", "mfx_batch_run_host", "mfx_batch_overlap",
     "mfx_alloc_pinned", "mfx_free_pinned",
     "mfx_set_stream", "mfx_synchronize", "mfx_profile_enable", "mfx_profile_read",
-    "mfx_dominant_kernel_name", "mfx_debug_read",
+    "mfx_dominant_kernel_name", "mfx_debug_read", "mfx_plan_create", "mfx_plan_set_aligned",
     "mfx_host_mel_table", "mfx_host_dct_matrix", "mfx_host_frame_count",
 )
 
@@ -123,6 +123,8 @@ def load_library():
     L.mfx_profile_enable.argtypes = [vp, C.c_int]
     L.mfx_profile_read.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_double), C.c_int]
     L.mfx_dominant_kernel_name.argtypes, L.mfx_dominant_kernel_name.restype = [vp], C.c_char_p
+    L.mfx_plan_create.argtypes = [C.POINTER(MfxConfig), C.POINTER(vp)]
+    L.mfx_plan_set_aligned.argtypes = [vp, C.c_int]
     L.mfx_debug_read.argtypes, L.mfx_debug_read.restype = [vp, C.c_int, vp, i64], i64
     L.mfx_host_mel_table.argtypes = [i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, fp, C.POINTER(i32)]
     L.mfx_host_dct_matrix.argtypes = [i32, i32, i32, C.c_float, fp]
@@ -205,6 +207,66 @@ def reference_window(window_size):
     i = np.arange(window_size, dtype=np.float64)
     inner = np.float32(0.56) - np.float32(0.46) * np.cos((2.0 * np.pi * i) / window_size)
     return (inner.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+
+
+def plan_kernel(window_size, shift, num_banks, sample_rate, ceps_len, want_c0=False, dyn=DYN_NONE, fft_size=0, channels=1,
+                aligned=True, engine=0, low_freq=64.0, high_freq=None, input_buffer_size=0):
+    """Which front-end kernel the batch entries run for a shape -- asked of a PLANNING handle (mfx_plan_create: the
+    library's own configuration checks, host-built tables and LDS sums, no device, nothing computed).  Works without a
+    GPU; returns the kernel's name as rocprofv3 prints it.  Raises MfxError for a configuration mfx_create refuses."""
+    L = load_library()
+    cfg = MfxConfig(int(input_buffer_size or 100 * shift + window_size), int(window_size), int(shift), int(num_banks),
+                    float(sample_rate), float(low_freq), float(sample_rate / 2 if high_freq is None else high_freq),
+                    int(ceps_len), int(bool(want_c0)), 22.0, NORM_NONE, int(dyn), 3, 3, 1, int(fft_size), int(channels), 1, 0,
+                    int(engine), 0)
+    h = C.c_void_p()
+    rc = L.mfx_plan_create(C.byref(cfg), C.byref(h))
+    if rc != 0:
+        raise MfxError(rc, "mfx_plan_create: " + L.mfx_status_string(rc).decode())
+    try:
+        L.mfx_plan_set_aligned(h, int(bool(aligned)))
+        return L.mfx_dominant_kernel_name(h).decode()
+    finally:
+        L.mfx_destroy(h)
+
+
+# Shape -> front-end kernel of the batch entries (DESIGN.md section 5 prints this table; tests/test_host.py pins it through
+# plan_kernel, tests/test_parity_gpu.py checks a real handle against it).  BASELINE.json configs first, then every row of
+# profiles/r03/shapes_beyond_baseline.txt and the limits of each kernel.
+KERNEL_TABLE = (
+    # (what, plan_kernel keyword arguments, kernel)
+    ("C1  a0001.wav, 16 kHz 25/10 ms, 512 pt, 26 mel, 13 MFCC + d + dd", dict(window_size=400, shift=160, num_banks=26, sample_rate=16000.0, ceps_len=13, dyn=DYN_ACC), "k_front512"),
+    ("C2 / C4  16 kHz 25/10 ms, 512 pt, 40 mel, 13 MFCC + d + dd", dict(window_size=400, shift=160, num_banks=40, sample_rate=16000.0, ceps_len=13, dyn=DYN_ACC), "k_front512"),
+    ("R   reference main() defaults: 15 mel, 12 MFCC + c0, CVN", dict(window_size=400, shift=160, num_banks=15, sample_rate=16000.0, ceps_len=12, want_c0=True), "k_front512"),
+    ("C3  16 kHz 25/10 ms zero padded to 1024 pt, 80 mel, 13 MFCC", dict(window_size=400, shift=160, num_banks=80, sample_rate=16000.0, ceps_len=13, fft_size=1024), "k_front1024"),
+    ("C5  44.1 kHz stereo, 1102/441, 2048 pt, 128 mel, 40 MFCC + d + dd", dict(window_size=1102, shift=441, num_banks=128, sample_rate=44100.0, ceps_len=40, dyn=DYN_ACC, channels=2), "k_front2048"),
+    ("C2 shape, odd shift 161 (unaligned build)", dict(window_size=400, shift=161, num_banks=40, sample_rate=16000.0, ceps_len=13, dyn=DYN_ACC, aligned=False), "k_front512"),
+    ("fbank-80 at 16 kHz (80 log mel energies, no DCT), 512 pt", dict(window_size=400, shift=160, num_banks=80, sample_rate=16000.0, ceps_len=0), "k_front512"),
+    ("8 kHz telephony 25/10 ms: 256 pt, zero-stuffed", dict(window_size=200, shift=80, num_banks=23, sample_rate=8000.0, ceps_len=13, dyn=DYN_ACC), "k_front512"),
+    ("8 kHz stereo, 256 pt", dict(window_size=200, shift=80, num_banks=23, sample_rate=8000.0, ceps_len=13, channels=2), "k_front512"),
+    ("16 kHz stereo, 512 pt", dict(window_size=400, shift=160, num_banks=40, sample_rate=16000.0, ceps_len=13, channels=2), "k_front512"),
+    ("11.025 kHz 25/10 ms: 512 pt", dict(window_size=276, shift=110, num_banks=40, sample_rate=11025.0, ceps_len=13), "k_front512"),
+    ("128-point transform (zero-stuffed twice over)", dict(window_size=128, shift=64, num_banks=20, sample_rate=8000.0, ceps_len=12), "k_front512"),
+    ("64-point transform (zero-stuffed three times over)", dict(window_size=64, shift=32, num_banks=12, sample_rate=8000.0, ceps_len=8), "k_front512"),
+    ("256 pt with the stuffed form switched off (MFX_ENGINE_NO_STUFF256)", dict(window_size=200, shift=80, num_banks=23, sample_rate=8000.0, ceps_len=13, engine=128), "k_front_wave"),
+    ("512 pt, more than 128 filters", dict(window_size=400, shift=160, num_banks=160, sample_rate=16000.0, ceps_len=13), "k_front_wave"),
+    ("22.05 kHz 25/10 ms: 1024 pt (552 taps, aligned frames)", dict(window_size=552, shift=220, num_banks=80, sample_rate=22050.0, ceps_len=13), "k_front1024"),
+    ("22.05 kHz fbank-80 (no DCT), 1024 pt", dict(window_size=552, shift=220, num_banks=80, sample_rate=22050.0, ceps_len=0), "k_front1024"),
+    ("32 kHz 25/10 ms: 1024 pt (800 taps)", dict(window_size=800, shift=320, num_banks=80, sample_rate=32000.0, ceps_len=13), "k_front1024"),
+    ("C3 shape, odd shift 161 (unaligned build)", dict(window_size=400, shift=161, num_banks=80, sample_rate=16000.0, ceps_len=13, fft_size=1024, aligned=False), "k_front1024"),
+    ("1024 pt, 800 taps on UNALIGNED frames", dict(window_size=800, shift=321, num_banks=80, sample_rate=32000.0, ceps_len=13, aligned=False), "k_front_reg"),
+    ("1024 pt, more than 80 filters", dict(window_size=400, shift=160, num_banks=96, sample_rate=16000.0, ceps_len=13, fft_size=1024), "k_front_reg"),
+    ("1024 pt, more than 16 columns with a DCT", dict(window_size=400, shift=160, num_banks=80, sample_rate=16000.0, ceps_len=20, fft_size=1024), "k_front_reg"),
+    ("1024 pt stereo", dict(window_size=552, shift=220, num_banks=80, sample_rate=22050.0, ceps_len=13, channels=2), "k_front_reg"),
+    ("C3 shape with k_front1024 switched off (MFX_ENGINE_NO_FRONT1024)", dict(window_size=400, shift=160, num_banks=80, sample_rate=16000.0, ceps_len=13, fft_size=1024, engine=1), "k_front_reg"),
+    ("44.1 kHz mono, odd shift 441 (any-alignment build)", dict(window_size=1102, shift=441, num_banks=128, sample_rate=44100.0, ceps_len=40, dyn=DYN_ACC, aligned=False), "k_front2048"),
+    ("48 kHz 25/10 ms: 2048 pt (1200 taps, 20-row build)", dict(window_size=1200, shift=480, num_banks=128, sample_rate=48000.0, ceps_len=40, dyn=DYN_ACC), "k_front2048"),
+    ("n_fft = win_length = 2048, hop 512 (32-row build)", dict(window_size=2048, shift=512, num_banks=128, sample_rate=44100.0, ceps_len=40), "k_front2048"),
+    ("C5 shape with k_front2048 switched off (MFX_ENGINE_NO_FRONT2048)", dict(window_size=1102, shift=441, num_banks=128, sample_rate=44100.0, ceps_len=40, dyn=DYN_ACC, channels=2, engine=4), "k_front_reg"),
+    ("4096 pt (50 ms at 48 kHz): spectrum + k_melcep", dict(window_size=2400, shift=480, num_banks=64, sample_rate=48000.0, ceps_len=13), "k_front_reg"),
+    ("4096 pt, 20 wide filters (ADVICE r3)", dict(window_size=2400, shift=480, num_banks=20, sample_rate=48000.0, ceps_len=12), "k_front_reg"),
+    ("any shape on the streaming interface's kernels (MFX_ENGINE_STREAM_KERNELS)", dict(window_size=400, shift=160, num_banks=40, sample_rate=16000.0, ceps_len=13, dyn=DYN_ACC, engine=8), "k_front512"),
+)
 
 
 ENGINE_NO_FRONT1024, ENGINE_FUSE_DELTA, ENGINE_NO_FRONT2048, ENGINE_STREAM_KERNELS, ENGINE_NORM_TWO_KERNELS = 1, 2, 4, 8, 16

@@ -205,8 +205,18 @@ int mfx_synchronize(mfx_handle *h);
  * around that kernel only).  enable=1 turns recording on; it is off by default. */
 int mfx_profile_enable(mfx_handle *h, int enable);
 int mfx_profile_read(mfx_handle *h, int32_t *launches, double *kernel_ms, int reset);
-/* name of the dominant kernel as it appears in rocprofv3's kernel trace */
+/* name of the dominant (front-end) kernel of the batch entries as it appears in rocprofv3's kernel trace: what the ONE
+ * dispatch rule of the library (choose_front, mfx_api.cpp) picks for this handle */
 const char *mfx_dominant_kernel_name(const mfx_handle *h);
+/* A PLANNING handle: mfx_create's own configuration checks, host-built tables and LDS sums with every device call left
+ * out -- it answers mfx_dominant_kernel_name and the geometry accessors (mfx_get_output_data_width,
+ * mfx_get_input_buffer_size, mfx_estimated_window_count, mfx_max_frames_out, mfx_fft_size) without a GPU and computes
+ * nothing; every other entry fails on it with MFX_ERR_DEVICE.  The shape -> kernel table of DESIGN.md is pinned through it
+ * (tests/test_host.py).  The reference has no analogue: it chooses its back end by a CLI switch (ASR_OCL.cpp:132-146).
+ * mfx_plan_set_aligned: whether the batch's frames lie on aligned sample pairs (mfx_batch_plan derives that from the
+ * caller's offsets on a real handle; default 1). */
+int mfx_plan_create(const mfx_config *cfg, mfx_handle **out);
+int mfx_plan_set_aligned(mfx_handle *h, int aligned);
 
 /* ---- host-side table builders (no device needed; the same code fills the tables the kernels
  *      read, exposed so that CPU-only tests can compare them with the oracle bit for bit) ---- */

@@ -3,11 +3,12 @@
  * See mfcc_oracle.h for scope and pinning status.  Citations are file:line in /root/reference.
  *
  * Arithmetic follows the reference's float32 expression order.  Where the reference calls an
- * unqualified libm name on a float (log/exp/sin/cos/atan/sqrt in mfcccpu.cpp:21-22,36,203,212)
- * the float overload is used by default, which is what the reference's own toolchain (MSVC, global
- * <cmath> overloads) resolves to; orc_set_libm_binding(o, 1) selects the C double functions instead,
- * which is how g++ compiles those lines -- and under which this file is bit-identical to the
- * reference's compiled mfcccpu.cpp (oracle/_ref/libref_mfcccpu.so, tests/test_ref_mfcccpu.py).
+ * unqualified libm name on a float (log/exp/sin/cos/atan/sqrt in mfcccpu.cpp:21-22,36,203,212; abs in
+ * normalizercpu.cpp:66) the float overload is used by default, which is what the reference's own toolchain (MSVC,
+ * global <cmath> overloads) resolves to -- and under which this file is bit-identical to the reference built here with
+ * that overload selection (oracle/_ref/libref_mfcccpu_f32.so: oracle/Makefile ref_f32).  orc_set_libm_binding(o, 1)
+ * selects the C double functions and int abs instead, which is how plain g++ compiles those lines -- and under which
+ * this file is bit-identical to oracle/_ref/libref_mfcccpu.so (tests/test_ref_mfcccpu.py, both).
  */
 #include "mfcc_oracle.h"
 

@@ -16,10 +16,16 @@
  *     do_delta, normalize, apply, get_output_data run as compiled; only its constructor / destructor / fft(), the sole
  *     users of libfftw3f (absent from this image), are never referenced and are dropped by the linker (--gc-sections; no
  *     fftwf_* symbol remains, no stand-in for FFTW is written).  See oracle/ref_mfcccpu_shim.cpp.
- *   With the reference's unqualified libm calls bound as g++ binds them (orc_set_libm_binding(o, 1)) this restatement is
- *   BIT-IDENTICAL to that library on every case of tests/refcases.py and on a randomised sweep (tests/test_ref_mfcccpu.py);
- *   under the reference's own toolchain binding (MSVC float overloads, the default here) no filter edge moves and rows
- *   stay within 5e-6 of the output scale.  The committed vectors are tests/golden/ref_mfcccpu_vectors.npz.
+ *   Both libraries exist in TWO builds, one per binding of the reference's UNQUALIFIED libm calls on floats
+ *   (mfcccpu.cpp:21-22,37,203,212; abs in normalizercpu.cpp:66):
+ *     - _ref/libref_mfcccpu_f32.so, libref_stages_f32.so (round 4): compiled with `-include math.h -include stdlib.h`, which
+ *       makes those calls select the FLOAT overloads -- the selection the reference's own toolchain (MSVC) makes.  This
+ *       restatement's DEFAULT arithmetic is BIT-IDENTICAL to that build on every case of tests/refcases.py (MINMAX
+ *       included), on filter() + dct() over synthetic spectra and on a randomised sweep (tests/test_ref_mfcccpu.py);
+ *       committed vectors tests/golden/ref_mfcccpu_vectors_f32.npz.  Same overload selection as MSVC, not the same C
+ *       runtime: logf / expf / atanf / sinf / cosf / sqrtf are glibc's.
+ *     - _ref/libref_mfcccpu.so, libref_stages.so: plain g++ (the C double functions, int abs(int)); this restatement under
+ *       orc_set_libm_binding(o, 1) is BIT-IDENTICAL to it (tests/golden/ref_mfcccpu_vectors.npz).
  *   Not pinned by execution, "by definition" instead: the transform at the FFTW call site (mfcccpu.cpp:114,187-190 -- the
  *   DFT, checked against numpy float64) and the DCT + lifter matrix block of the constructor (mfcccpu.cpp:118-136, explicit
  *   sinf / cosf: no toolchain question).

@@ -2,8 +2,10 @@
 
 Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
 this module.  It loads ``oracle/liboracle.so`` (this repo's C restatement of the reference's
-CPU path, ``oracle/mfcc_oracle.c``) and, when present, ``oracle/_ref/libref_stages.so`` (the
-reference's own segmenter/delta/normalizer/base objects, built in place from /root/reference).
+CPU path, ``oracle/mfcc_oracle.c``) and, when present, the libraries under ``oracle/_ref/`` (the
+reference's own translation units, built in place from /root/reference by ``make -C oracle ref``:
+``libref_stages*.so`` segmenter/delta/normalizer/base objects, ``libref_mfcccpu*.so`` mfcccpu.cpp without FFTW;
+``*_f32`` = the build whose unqualified libm calls select the float overloads, as the reference's toolchain does).
 """
 import ctypes as C
 import os

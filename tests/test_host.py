@@ -360,7 +360,7 @@ def test_sanitizer_targets_run_clean():
 
 
 def test_front1024_decimation_identity():
-    """The factorisation k_front1024 computes (csrc/mfx_kernels.hip), restated in numpy in double precision: for a real
+    """The factorisation k_front1024 computes (csrc/mfx_front512.hip), restated in numpy in double precision: for a real
     frame that is zero from sample 512 on, the 1024-point DFT is two 256-point complex DFTs of the packed samples
     z[m] = x[2m] + i x[2m+1] -- even bins through the usual real split of FFT256(z), odd bins through the same split
     arithmetic applied to V = FFT256(z W_512^m) with partner bin 255 - k and twiddle -i W_1024^(2k+1); the paired form
@@ -513,3 +513,45 @@ def test_bench_collective_default_is_gloo():
     assert bench.RCCL_PROBE_TIMEOUT_S <= 60
     for name, (label, source) in bench.BOUND_DIAGNOSED.items():
         assert os.path.exists(os.path.join(ROOT, source.split(":")[0])), source
+
+
+def test_shape_to_kernel_table(pkg):
+    """ONE table of shape -> front-end kernel of the batch entries (asr-featext-opencl_amd/mfcc.py KERNEL_TABLE; DESIGN.md
+    section 5 prints it): the five BASELINE.json configurations, every row of profiles/r03/shapes_beyond_baseline.txt and the
+    limits of each kernel, asked of PLANNING handles -- the library's own dispatch rule (choose_front, mfx_api.cpp: the function
+    the batch entry launches from) on its own host-built tables, without a device.  tests/test_parity_gpu.py checks real
+    handles against the same table."""
+    names = set()
+    for what, kw, want in pkg.KERNEL_TABLE:
+        assert pkg.plan_kernel(**kw) == want, what
+        names.add(want)
+    assert names == {"k_front512", "k_front1024", "k_front2048", "k_front_reg", "k_front_wave"}
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for what, kw, want in pkg.KERNEL_TABLE:   # the printed table is this table
+        assert "| %s | `%s` |" % (what, want) in design, what
+
+
+def test_planning_handle_computes_nothing(pkg):
+    """mfx_plan_create: geometry and the kernel choice only -- every entry that would need the device fails with
+    MFX_ERR_DEVICE (-5 family) instead of computing; configurations mfx_create refuses are refused here too."""
+    L = pkg.load_library()
+    cfg = pkg.MfxConfig(8000, 400, 160, 40, 16000.0, 64.0, 8000.0, 13, 0, 22.0, 0, 2, 3, 3, 1, 0, 1, 1, 0, 0, 0)
+    h = C.c_void_p()
+    assert L.mfx_plan_create(C.byref(cfg), C.byref(h)) == 0
+    assert L.mfx_get_output_data_width(h) == 39 and L.mfx_fft_size(h) == 512
+    assert L.mfx_get_input_buffer_size(h) == 48 * 160 + 240 and L.mfx_estimated_window_count(h, 16000) == 98
+    w = np.ones(400, np.float32)
+    n = C.c_int32()
+    pcm = np.zeros(8000, np.int16)
+    out = np.zeros(39 * 64, np.float32)
+    rcs = [L.mfx_set_window(h, w.ctypes.data_as(C.POINTER(C.c_float))),
+           L.mfx_set_input(h, pcm.ctypes.data_as(C.POINTER(C.c_int16)), 8000, C.byref(n)),
+           L.mfx_apply(h), L.mfx_flush(h, C.byref(n)),
+           L.mfx_get_output_data(h, out.ctypes.data_as(C.POINTER(C.c_float)), 1), L.mfx_synchronize(h)]
+    assert len(set(rcs)) == 1 and rcs[0] < 0 and b"planning handle" in L.mfx_last_error(h)
+    assert rcs[0] == L.mfx_create(C.byref(cfg), 9999, C.byref(C.c_void_p()))   # = MFX_ERR_DEVICE
+    L.mfx_destroy(h)
+    bad = pkg.MfxConfig(8000, 400, 160, 40, 16000.0, 64.0, 8000.0, 13, 0, 0.0, 0, 2, 3, 3, 1, 0, 1, 1, 0, 0, 0)   # lifter 0
+    assert L.mfx_plan_create(C.byref(bad), C.byref(h)) != 0
+    with pytest.raises(pkg.MfxError):
+        pkg.plan_kernel(window_size=8192, shift=160, num_banks=40, sample_rate=16000.0, ceps_len=13)   # > 4096 points

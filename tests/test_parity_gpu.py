@@ -982,6 +982,21 @@ def test_few_wide_filters_on_a_4096_point_transform(pkg, orc, nb):
         assert_close(m.get_output_data_alpha(i, n), o.get_output_data(n), "4096 points, %d filters, alpha %.2f" % (nb, a), groups=3)
 
 
+def test_real_handles_agree_with_the_shape_to_kernel_table(pkg):
+    """Every row of mfcc.KERNEL_TABLE on a REAL handle: mfx_dominant_kernel_name after mfx_batch_plan (which derives the
+    alignment from the caller's offsets) names the kernel the planning handle named (tests/test_host.py)."""
+    for what, kw, want in pkg.KERNEL_TABLE:
+        sr = kw["sample_rate"]
+        m = pkg.MfccHip(100 * kw["shift"] + kw["window_size"], kw["window_size"], kw["shift"], kw["num_banks"], sr, 64.0, sr / 2,
+                        kw["ceps_len"], kw.get("want_c0", False), 22.0, 0, kw.get("dyn", 0), 3, 3, True, device=0,
+                        fft_size=kw.get("fft_size", 0), channels=kw.get("channels", 1), engine=kw.get("engine", 0))
+        m.set_window(pkg.reference_window(kw["window_size"]))
+        n = 40 * kw["shift"] + kw["window_size"]
+        m.batch_plan([0 if kw.get("aligned", True) else 1], [n])
+        assert m.dominant_kernel_name() == want, what
+        m.close()
+
+
 @pytest.mark.parametrize("norm,dyn", [(0, 2), (2, 2), (0, 0)])
 def test_small_block_copy_kernels_same_bits_as_dma(pkg, orc, norm, dyn):
     """Streaming interface, blocks under 1 MB: the block goes to the device, the carried tail to the other carry buffer and
