@@ -257,6 +257,66 @@ def cpu_baseline(orc, wl, pcm_host, window, budget_s=12.0):
     }
 
 
+KERNEL_SHORT_NAMES = ("k_front2048", "k_front512", "k_front1024", "k_front_reg", "k_front_wave", "k_delta16", "k_delta4", "k_delta",
+                      "k_melcep", "k_norm_seg", "k_norm_stats", "k_norm_finalize", "k_norm_apply")
+
+
+def measure_traffic_live(argv_tail, timeout_s=75):
+    """HBM bytes per launch of every kernel of the step, measured NOW: two child runs of this same bench (3 steps, no settle, no
+    CPU baseline) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (one counter per pass, kernel trace only -- the form
+    MI355X_MICROARCH.md prescribes), after the timed region.  Corrections as tools/pmc_run.sh: both counters are in KiB; on
+    gfx950 FETCH_SIZE reports half of the bytes of a coalesced streaming read (x2), WRITE_SIZE is exact at 32-byte sectors.
+    Returns {kernel: {read, write, total, launches}} or None (no rocprofv3, a pass failed or ran out of time: the caller
+    then falls back to the tracked profiles/traffic_latest.json and says so)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if tool is None:
+        return None
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="mfx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", MFX_BENCH_LIVE_TRAFFIC="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [tool, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--settle-ms", "0", "--no-cpu-baseline"] + argv_tail
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            rows = 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    name = row.get("Kernel_Name", "")
+                    if "mfx::" not in name or row.get("Counter_Name") != counter:
+                        continue
+                    short = next((n for n in KERNEL_SHORT_NAMES if n in name), None)
+                    if short is None:
+                        continue
+                    e = out.setdefault(short, {"FETCH_SIZE": [], "WRITE_SIZE": []})
+                    e[counter].append(float(row["Counter_Value"]))
+                    rows += 1
+            if rows == 0:
+                return None
+    except Exception:   # noqa: BLE001 -- timeouts, a missing tool, an unreadable file: the tracked file is the fallback
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for k, e in out.items():
+        if not e["FETCH_SIZE"] or not e["WRITE_SIZE"]:
+            return None
+        rd = 2 * 1024 * sum(e["FETCH_SIZE"]) / len(e["FETCH_SIZE"])
+        wr = 1024 * sum(e["WRITE_SIZE"]) / len(e["WRITE_SIZE"])
+        res[k] = {"read": rd, "write": wr, "total": rd + wr, "launches": len(e["FETCH_SIZE"])}
+    return res or None
+
+
 def wl_frames(wl):
     per = (wl["utt_samples"] - (wl["W"] - wl["S"])) // wl["S"]
     return per * wl["n_utt"]
@@ -313,6 +373,9 @@ def build_parser():
     ap.add_argument("--collective", default="gloo", choices=["gloo", "rccl"],
                     help="N > 1: what carries the barrier and the max-over-ranks (no collective is on the data path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="take roofline.traffic from the tracked profiles/traffic_latest.json instead of measuring it after the "
+                         "timed region (two child runs under rocprofv3 --pmc, ~10 s each; N = 1 only)")
     ap.add_argument("--engine", type=int, default=0, help="mfx_config.engine bits (A/B of equivalent kernels; 0 = the library's choice)")
     ap.add_argument("--tail-split", type=int, default=0, help="mfx_config.tail_split (0 = default, -1 = off)")
     ap.add_argument("--overlap", action="store_true",
@@ -484,8 +547,20 @@ def main():
     # this same command and corrected as MI355X_MICROARCH.md prescribes): NOT measured in this run -- read from the
     # tracked profiles/traffic_latest.json, per workload and kernel, and labelled so
     traffic, traffic_source, step_traffic = None, None, None
+    live = None
+    if (world == 1 and not args.no_live_traffic and not args.no_cpu_baseline and os.environ.get("MFX_BENCH_LIVE_TRAFFIC", "1") != "0"):
+        # (the full default line only: A/B loops, profiler runs and the multi-rank path keep the tracked file)
+        tail = ["--workload", args.workload, "--engine", str(args.engine), "--tail-split", str(args.tail_split)]
+        live = measure_traffic_live(tail)
+    if live and kname in live:
+        front = max(live[kname]["launches"], 1)
+        traffic = live[kname]["total"]
+        traffic_source = ("measured in this run, after the timed region: two child runs of this command (3 steps) under "
+                          "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (x2 / x1, KiB; MI355X_MICROARCH.md), per launch")
+        step_traffic = {"bytes_per_step": sum(v["total"] * v["launches"] / front for v in live.values()),
+                        "kernels": {k: v["total"] for k, v in live.items()}, "source": traffic_source}
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
+    if traffic is None and os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             ent = tj.get(args.workload) if isinstance(tj.get(args.workload), dict) else tj

@@ -1202,6 +1202,31 @@ def test_bench_self_launch_two_ranks_strong_scaling():
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
 
 
+def test_bench_measures_hbm_traffic_in_the_run():
+    """Round 4: the default line's roofline.traffic is MEASURED by bench.py itself -- two child runs of the same command under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` after the timed region -- not copied from a tracked file; the whole step's
+    counter bytes stand beside its algorithmic bytes.  (Tiny workload here: the figures are launch overheads, the plumbing is
+    what is checked.)"""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("no rocprofv3 on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MFX_BENCH_LIVE_TRAFFIC")}
+    env["MFX_CPU_THREADS"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--settle-ms", "5",
+                        "--workload", "T"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    rf = d["roofline"]
+    assert rf["traffic_source"].startswith("measured in this run"), rf["traffic_source"]
+    assert rf["traffic"] > 0 and set(rf["whole_path"]["traffic_kernels"]) == {"k_front512", "k_delta16"}
+    assert rf["whole_path"]["traffic"] >= rf["traffic"] and rf["whole_path"]["traffic_over_algorithmic"] > 0.5
+    assert d["cpu_baseline"]["kind"] == "port"
+
+
 def test_bench_reference_defaults_workload_runs_the_normaliser():
     """`--workload R` = the reference main()'s defaults (15 banks, 12 + c0, CVN): a bench line whose step contains the
     normaliser kernels (steps kept tiny here; the timed evidence lives in profiles/)."""
