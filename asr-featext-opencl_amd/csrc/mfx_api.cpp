@@ -652,10 +652,16 @@ int create_impl(const mfx_config *cfg, int hip_device, mfx_handle **out)
         std::vector<float> tw;
         build_twiddles(h->W2 / 2, h->W2 / 2, tw); // W_M^k, k < M (radix-4 stages use k, 2k, 3k)
         if (upload(h->d_twid_half, tw) != hipSuccess) return bail(MFX_ERR_DEVICE);
+        // Split twiddles -i W_N^k, k <= N / 2.  The zero-stuffed forms (256 / 128 / 64 points on k_front512) run the 512-POINT
+        // transform and its split: the kernel stages W_512^k for k < 128 whatever W2 is.  (Until round 4 this table had
+        // W2 / 2 + 1 entries: at 128 and 64 points the kernel read 63 / 95 entries past its end.  The split's difference
+        // term is rounding noise there, so fresh -- zero -- memory hid it; stale memory with large values did not:
+        // found by tools/fuzz_all.py, seed 3 case 17.)
+        const int WS = h->stuff256 ? 512 : h->W2;
         std::vector<float> ws;
-        build_twiddles(h->W2, h->W2 / 2 + 1, ws); // W_{W2}^k
+        build_twiddles(WS, WS / 2 + 1, ws); // W_{WS}^k
         std::vector<float> split(ws.size());
-        for (int k = 0; k <= h->W2 / 2; ++k) { // -i * W = (wi, -wr)
+        for (int k = 0; k <= WS / 2; ++k) { // -i * W = (wi, -wr)
             split[2 * k] = ws[2 * k + 1];
             split[2 * k + 1] = -ws[2 * k];
         }
@@ -1183,7 +1189,11 @@ extern "C" int mfx_set_input(mfx_handle *h, const int16_t *pcm, int32_t samples,
         window_count = wcnd - D;
         if (window_count <= 0) return fail(h, MFX_ERR_WINDOW_COUNT, kMsgWindow);
         const int processed = (window_count - D) * S + W - S;
-        if (processed <= 0) return fail(h, MFX_ERR_PROCESSED, kMsgProcessed);
+        // B13: a first block of fewer than 2 D frames.  The reference guards `processed <= 0` only (segmentercpu.cpp:70-71);
+        // for D < frames < 2 D with W - S > (D - window_count) S it goes on and copies its carry-over from BEFORE the start
+        // of its buffer (m_tmpbuffer + samples - m_remaining_samples is negative, :72-73) -- undefined there, refused here
+        // with the message the reference's own guard carries.
+        if (processed <= 0 || window_count < D) return fail(h, MFX_ERR_PROCESSED, kMsgProcessed);
         int rc = stream_front(h, wcnd);
         if (rc != MFX_OK) return rc;
         h->remaining = samples - processed + W - S;

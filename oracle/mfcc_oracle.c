@@ -571,7 +571,10 @@ static int seg_set_input(orc_mfcc *o, const short *data_in, int samples, int *wi
         if (*window_count <= 0) return ORC_ERR_WINDOW_COUNT;
         orc_segment(o->tmpbuffer, o->window, W, o->window_size2, S, *wcnd, o->data);
         int processed = (*window_count - D) * S + W - S;
-        if (processed <= 0) return ORC_ERR_PROCESSED;
+        /* with fewer than 2 D frames in a first block the reference's carry-over starts BEFORE its buffer
+         * (segmentercpu.cpp:72-73: m_tmpbuffer + samples - m_remaining_samples < m_tmpbuffer) unless its `processed <= 0`
+         * guard happens to fire: undefined behaviour there; refused here (and by the product) with that guard's error. */
+        if (processed <= 0 || *window_count < D) return ORC_ERR_PROCESSED;
         o->remaining_samples = samples - processed + W - S;
         memmove(o->tmpbuffer, o->tmpbuffer + samples - o->remaining_samples, sizeof(short) * o->remaining_samples);
         o->flushed = 0;

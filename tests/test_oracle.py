@@ -292,3 +292,24 @@ def test_run_batch_equals_run_utterance(orc):
     got = orc.run_batch(cfg, pcm, n_threads=2)
     for u in range(4):
         assert np.array_equal(got[u], orc.run_utterance(cfg, pcm[u], bug_compat=False))
+
+
+def test_first_block_shorter_than_two_delta_contexts_is_refused(orc):
+    """a first block with D < frames < 2 D makes the reference copy its carry-over from before the start of its
+    buffer (segmentercpu.cpp:72-73) unless its `processed_samples <= 0` guard (:70-71) happens to fire.  The checker refuses
+    every such block with that guard's error; 2 D frames and more are accepted."""
+    W, S = 62, 30
+    w = orc.reference_window(W)
+    pcm = np.zeros(4000, np.int16)
+    for (l1, l2, blk_frames, ok) in ((3, 1, 7, False), (3, 1, 8, True), (3, 3, 11, False), (3, 3, 12, True), (3, 3, 6, False)):
+        D = l1 + l2
+        blk = blk_frames * S + W - S
+        cfg = orc.make_config(blk, window_size=W, shift=S, num_banks=16, sample_rate=8000.0, ceps_len=4, want_c0=True,
+                              dyn=orc.DYN_ACC, delta_l1=l1, delta_l2=l2)
+        o = orc.OracleMfcc(cfg, w)
+        if ok:
+            assert o.set_input(pcm[:blk]) == blk_frames - D
+        else:
+            with pytest.raises(RuntimeError):
+                o.set_input(pcm[:blk])
+        o.close()

@@ -997,6 +997,54 @@ def test_real_handles_agree_with_the_shape_to_kernel_table(pkg):
         m.close()
 
 
+@pytest.mark.parametrize("W,S,nb,nc", [(91, 19, 32, 6), (122, 102, 15, 7), (62, 30, 16, 4), (44, 40, 12, 5)])
+def test_zero_stuffed_forms_read_no_table_memory_they_do_not_own(pkg, orc, W, S, nb, nc):
+    """Found by tools/fuzz_all.py (seed 3, case 17): at 128 and 64 points the zero-stuffed form of k_front512 staged 128 split
+    twiddles from a table of W2 / 2 + 1 = 65 / 33 entries.  The split's difference term is rounding noise in that form, so
+    whatever finite, small values lay behind the table did no harm -- fresh device memory is zero -- but stale memory with
+    large values turned the noise into garbage (2.4 x the output scale).  Device memory is poisoned here (a 1 GiB tensor of
+    1e30, released to the driver) before the handle allocates its tables; 128- and 64-point transforms, batch entry."""
+    import torch
+    x = torch.full((1 << 28,), 1e30, dtype=torch.float32, device="cuda:0")
+    y = [torch.full((n,), 1e30, dtype=torch.float32, device="cuda:0") for n in (128, 256, 512, 1024, 4096) for _ in range(64)]
+    torch.cuda.synchronize()
+    del x, y
+    torch.cuda.empty_cache()
+    lens = [716, 547, 288, 575]
+    offs = [2, 721, 1271, 1559]
+    pcm = synth_utterance(2135, 17, sr=16000.0)
+    m, cfg, w = make_pair(pkg, orc, 4000, W=W, S=S, nb=nb, sr=16000.0, nc=nc, dyn=0, bug_compat=False)
+    assert m.dominant_kernel_name() == "k_front512" and m.fft_size() in (64, 128)
+    m.set_alpha(0.95)
+    rows, total = m.batch_plan(offs, lens)
+    got = m.batch_run_host(pcm)
+    for u, n in enumerate(lens):
+        want = orc.run_utterance(cfg, pcm[offs[u]:offs[u] + n], w, alpha=0.95, bug_compat=False)
+        assert_close(got[rows[u]:rows[u] + want.shape[0]], want, "W %d utt %d" % (W, u))
+
+
+@pytest.mark.parametrize("engine", [0, 32])
+def test_first_block_shorter_than_two_delta_contexts_is_refused(pkg, orc, engine):
+    """DESIGN.md B13 (found by tools/fuzz_all.py as a host crash): a first block with D < frames < 2 D frames left the carried
+    tail starting 30 samples BEFORE the staging buffer (engine 0: copy kernels through pinned staging) / before the device carry
+    buffer (engine 32: DMA commands) -- as the reference does (segmentercpu.cpp:72-73, undefined there).  Refused now, with the
+    reference's own guard message; the handle stays usable; blocks of 2 D frames and more stream as before."""
+    W, S, l1, l2 = 62, 30, 3, 1
+    D = l1 + l2
+    pcm = synth_utterance(1295, 91, sr=8000.0)
+    mk = lambda blk: make_pair(pkg, orc, blk, W=W, S=S, nb=16, sr=8000.0, nc=4, c0=True, dyn=2, l1=l1, l2=l2, engine=engine)
+    m, cfg, w = mk(271)                       # 7 frames per block: 3 delivered, carry-over would start at sample -30
+    assert m.get_input_buffer_size() == 7 * S + W - S
+    with pytest.raises(pkg.MfxError, match="Processed samples"):
+        m.set_input(pcm[:m.get_input_buffer_size()])
+    with pytest.raises(RuntimeError):
+        orc.OracleMfcc(cfg, w).set_input(pcm[:m.get_input_buffer_size()])
+    m2, cfg2, _ = mk(2 * D * S + W - S + 5)   # 2 D frames per block: accepted
+    got = m2.process_stream(pcm)
+    want = orc.run_utterance(cfg2, pcm, w)
+    assert_close(got, want, "blocks of exactly 2 D frames", groups=3)
+
+
 @pytest.mark.parametrize("norm,dyn", [(0, 2), (2, 2), (0, 0)])
 def test_small_block_copy_kernels_same_bits_as_dma(pkg, orc, norm, dyn):
     """Streaming interface, blocks under 1 MB: the block goes to the device, the carried tail to the other carry buffer and

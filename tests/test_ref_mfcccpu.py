@@ -204,9 +204,10 @@ def test_live_reference_randomised_sweep(orc, binding):
         alpha = float(rng.choice([1.0, 0.85, 0.93, 1.07, 1.15]))
         n = int(rng.integers(20, 60)) * S + W
         D = (l1 if dyn else 0) + (l2 if dyn == 2 else 0)
-        # the reference throws when a first block holds no more than D frames, and overruns its buffers when dyn is off
-        # and the carry-over is long: keep the blocks inside what it supports
-        blk = int(rng.integers((D + 3) * S + W, n + S))
+        # the reference throws when a first block holds no more than D frames, reads before its carry buffer when it holds
+        # fewer than 2 D, and overruns its buffers when dyn is off and the carry-over is long (B8): keep the
+        # blocks inside what it supports
+        blk = int(rng.integers((2 * D + 3) * S + W, max(n + S, (2 * D + 4) * S + W)))
         if dyn == 0 and W - S > 2 * S:
             blk = n + S
         case = dict(name="rand%d" % trial, pcm=("synth", n, 1000 + trial, sr), ibs=blk, alpha=alpha, window=None,
