@@ -1275,6 +1275,22 @@ def test_bench_measures_hbm_traffic_in_the_run():
     assert d["cpu_baseline"]["kind"] == "port"
 
 
+@pytest.mark.parametrize("tool,args", [("fuzz_all.py", ["1", "60"]), ("fuzz_api.py", ["1", "25"])])
+def test_differential_fuzzers_find_nothing(tool, args):
+    """tools/fuzz_all.py: random shapes over every transform size and front-end kernel, batch entry + streaming interface against
+    the checker (north-star bar, or 4 x the checker's own float32 noise where that is larger).  tools/fuzz_api.py: the library's
+    own equivalence claims (engine bits that promise the same bits, apply_alphas == set_alpha + apply, handle reuse after flush,
+    batch on the streaming kernels == streaming rows) and ragged / empty / replaced batch plans.  Round 4 found two bugs with
+    them within minutes (the zero-stuffed forms' split table); a short run of each stays in the suite."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", tool)] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "0 failures" in r.stdout.splitlines()[-1]
+
+
 def test_bench_reference_defaults_workload_runs_the_normaliser():
     """`--workload R` = the reference main()'s defaults (15 banks, 12 + c0, CVN): a bench line whose step contains the
     normaliser kernels (steps kept tiny here; the timed evidence lives in profiles/)."""
