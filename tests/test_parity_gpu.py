@@ -1275,6 +1275,38 @@ def test_bench_measures_hbm_traffic_in_the_run():
     assert d["cpu_baseline"]["kind"] == "port"
 
 
+@pytest.mark.parametrize("norm,dyn", [(0, 2), (1, 0), (2, 2)])
+def test_more_utterances_than_one_grid_dimension_holds(pkg, orc, norm, dyn):
+    """66 000 utterances in one plan: the delta and normaliser launchers walk the segment list in pieces of 65 535 (grid.y);
+    utterances on both sides of that seam, and the last one, against the checker (mfcccpu.cpp:234-282 per utterance)."""
+    n_utt, n = 66000, 1360                      # 7 frames each
+    rng = np.random.default_rng(66)
+    pcm = (3000.0 * rng.standard_normal(n_utt * n)).astype(np.int16)
+    m, cfg, w = make_pair(pkg, orc, n + 800, nb=26, norm=norm, dyn=dyn, l1=1, l2=1, nad=True, bug_compat=False)
+    offs = np.arange(n_utt, dtype=np.int64) * n
+    rows, total = m.batch_plan(offs, np.full(n_utt, n, dtype=np.int64))
+    assert total == 7 * n_utt
+    got = m.batch_run_host(pcm)
+    g = groups_of(dyn)
+    for u in (0, 1, 65534, 65535, 65536, 65537, n_utt - 1):
+        seg = pcm[u * n:(u + 1) * n]
+        if norm == 0:
+            want = orc.run_utterance(cfg, seg, w, bug_compat=False)
+        else:   # the utterance as ONE block, flush rows at their place (batch_norm_stats = 0: DESIGN.md B11)
+            o = orc.OracleMfcc(cfg, w, bug_compat=False)
+            k = o.set_input(seg)
+            o.apply()
+            parts = [o.get_output_data(k)]
+            kf = o.flush()
+            if kf > 0:
+                o.apply()
+                parts.append(o.get_output_data(kf))
+            want = np.concatenate(parts)
+            o.close()
+        tol = dict() if norm == 0 else dict(tol_max=2e-4, tol_l2=2e-4)   # (7-row statistics: the exact criterion is the three-part check)
+        assert_close(got[rows[u]:rows[u] + 7], want, "utterance %d of 66 000" % u, groups=g, **tol)
+
+
 @pytest.mark.parametrize("tool,args", [("fuzz_all.py", ["1", "60"]), ("fuzz_api.py", ["1", "25"])])
 def test_differential_fuzzers_find_nothing(tool, args):
     """tools/fuzz_all.py: random shapes over every transform size and front-end kernel, batch entry + streaming interface against
