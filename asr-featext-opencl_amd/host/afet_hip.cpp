@@ -132,7 +132,9 @@ Wav read_wav(const std::string &path)
         }
         pos += (size_t)8 + sz + (sz & 1);
     }
-    if (!have_fmt || w.pcm.empty()) throw std::runtime_error("Error while loading \"" + path + "\"");
+    // (a fmt chunk that announces 0 channels or a rate of 0 is refused like an unreadable file: the downmix divides by the
+    // channel count -- found reading the parser beside tools/fuzz_all.py's finds, round 4)
+    if (!have_fmt || w.channels < 1 || w.sample_rate <= 0 || w.pcm.empty()) throw std::runtime_error("Error while loading \"" + path + "\"");
     return w;
 }
 
@@ -525,6 +527,9 @@ void worker(const Options &o, int device, float sr, const std::vector<std::strin
 {
     try {
         const long W = (long)(sr * o.window_ms * 1e-3), S = (long)(sr * o.shift_ms * 1e-3);
+        // (a header that announces a sample rate of a few Hz -- found by mutating the reference's own sample1.wav, round 4 --
+        // makes the window or the shift shorter than one sample: refused here, before anything divides by the shift)
+        if (W < 1 || S < 1) throw std::runtime_error("window or shift shorter than one sample at this sample rate");
         // The extractor (HIP start-up, code object load, tables: 0.1-0.3 s of a fresh process) is created on a helper
         // thread while this one claims and reads the first batch of files: reading needs nothing from the device.
         auto make_param = [&] {

@@ -341,6 +341,14 @@ def test_cpp_driver_rejects_truncated_wave(tmp_path):
     bad.write_bytes(b"RIFF" + (36).to_bytes(4, "little") + b"WAVE" + b"fmt " + (16).to_bytes(4, "little") + b"\x01\x00\x01\x00")
     r = subprocess.run([exe, str(bad), str(tmp_path / "o.txt")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 1 and "truncated fmt chunk" in r.stderr
+    # a well-formed header that announces ZERO channels (the downmix divides by the channel count) / a rate of 0
+    for nch, rate in ((0, 16000), (1, 0)):
+        z = tmp_path / ("zero_%d_%d.wav" % (nch, rate))
+        z.write_bytes(b"RIFF" + (44).to_bytes(4, "little") + b"WAVE" + b"fmt " + (16).to_bytes(4, "little") + (1).to_bytes(2, "little") +
+                      nch.to_bytes(2, "little") + rate.to_bytes(4, "little") + (32000).to_bytes(4, "little") + (2).to_bytes(2, "little") +
+                      (16).to_bytes(2, "little") + b"data" + (8).to_bytes(4, "little") + bytes(8))
+        r = subprocess.run([exe, str(z), str(tmp_path / "o.txt")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 1 and "Error while loading" in r.stderr, (r.returncode, r.stderr)
     sph = tmp_path / "cut.sph"
     sph.write_bytes(b"NIST_1A\n99999999")
     r = subprocess.run([exe, str(sph), str(tmp_path / "o.txt")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -555,3 +563,16 @@ def test_planning_handle_computes_nothing(pkg):
     assert L.mfx_plan_create(C.byref(bad), C.byref(h)) != 0
     with pytest.raises(pkg.MfxError):
         pkg.plan_kernel(window_size=8192, shift=160, num_banks=40, sample_rate=16000.0, ceps_len=13)   # > 4096 points
+
+
+def test_cpp_driver_survives_mutated_headers():
+    """tools/fuzz_wav.py: 300 mutants of the reference's own sound files' headers (random bytes and fields, zeroed fields,
+    truncations) -- the driver ends with a message and an exit code, never by a signal.  Round 4 found two SIGFPEs this way
+    (0 channels in a fmt chunk; a 1 Hz SPHERE header: window and shift of 0 samples).  Without a GPU the well-formed mutants stop
+    at the extractor's constructor; on the GPU box they run through."""
+    exe = os.path.join(ROOT, "asr-featext-opencl_amd", "host", "afet_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_wav
+    assert fuzz_wav.run(seed=5, mutants=300, verbose=False) == 0
