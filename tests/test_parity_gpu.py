@@ -1307,12 +1307,15 @@ def test_more_utterances_than_one_grid_dimension_holds(pkg, orc, norm, dyn):
         assert_close(got[rows[u]:rows[u] + 7], want, "utterance %d of 66 000" % u, groups=g, **tol)
 
 
-@pytest.mark.parametrize("tool,args", [("fuzz_all.py", ["1", "60"]), ("fuzz_api.py", ["1", "25"])])
+@pytest.mark.parametrize("tool,args", [("fuzz_all.py", ["1", "60"]), ("fuzz_all.py", ["2", "40", "wide"]), ("fuzz_api.py", ["1", "25"]),
+                                       ("fuzz_calls.py", ["1", "25"])])
 def test_differential_fuzzers_find_nothing(tool, args):
     """tools/fuzz_all.py: random shapes over every transform size and front-end kernel, batch entry + streaming interface against
     the checker (north-star bar, or 4 x the checker's own float32 noise where that is larger).  tools/fuzz_api.py: the library's
     own equivalence claims (engine bits that promise the same bits, apply_alphas == set_alpha + apply, handle reuse after flush,
-    batch on the streaming kernels == streaming rows) and ragged / empty / replaced batch plans.  Round 4 found two bugs with
+    batch on the streaming kernels == streaming rows) and ragged / empty / replaced batch plans.  tools/fuzz_calls.py: random
+    call sequences on the streaming interface, legal steps mirrored on the checker, illegal ones (no block, too many rows, NULL
+    pointers, oversized blocks ...) thrown in between: status codes, no crash, state intact.  Round 4 found two bugs with
     them within minutes (the zero-stuffed forms' split table); a short run of each stays in the suite."""
     import subprocess
     import sys
