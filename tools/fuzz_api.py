@@ -7,7 +7,8 @@ the claim is "the same bits" or "the same rows"):
   2. mfx_apply_alphas == rounds of mfx_set_alpha + mfx_apply (same bits), each against the checker;
   3. one handle, several files: set_input* -> flush -> set_input* ... (DESIGN.md B7) == a fresh handle per file;
   4. ragged batches with utterances of 0 frames, of fewer than 2 D frames (whole-utterance formulas: the float64 restatement)
-     and ordinary ones in one plan; empty plans; plans replaced on a live handle.
+     and ordinary ones in one plan; empty plans; plans replaced on a live handle;
+  5. the device entry: consecutive batches with mfx_batch_overlap on == off (same bits), == the host entry.
 
     python tools/fuzz_api.py [seed] [cases]
 """
@@ -171,6 +172,32 @@ for case in range(n_cases):
                 if not okc:
                     notes.append("batch vs checker (file %d): %s" % (u, why))
                     break
+
+        # 1d. device entry: consecutive batches with the delta tail of batch i overlapping the front end of batch i + 1
+        # (mfx_batch_overlap: second stream, double-buffered statics) -- every batch the bits of the plain run, different PCM
+        # per batch (a race between a tail and the next front end would mix them)
+        import torch
+        dev = torch.device("cuda", 0)
+        mo = mk(big, bug_compat=False)
+        mo.set_window(window)
+        rows_o, total_o = mo.batch_plan(offs, [len(f) for f in files])
+        pcms = [torch.from_numpy(np.roll(pcm, 17 * i).copy()).to(dev) for i in range(4)]
+        outs_plain, outs_ovl = [], []
+        for mode, sink in ((False, outs_plain), (True, outs_ovl)):
+            mo.batch_overlap(mode)
+            bufs = [torch.zeros((max(total_o, 1), mo.get_output_data_width()), dtype=torch.float32, device=dev) for _ in range(4)]
+            for i in range(4):
+                mo.batch_run_device(pcms[i].data_ptr(), pcm.size, bufs[i].data_ptr())
+            mo.synchronize()
+            sink.extend(b.cpu().numpy() for b in bufs)
+        mo.batch_overlap(False)
+        mo.close()
+        for i in range(4):
+            if not np.array_equal(outs_plain[i], outs_ovl[i], equal_nan=True):
+                notes.append("overlapped batches: batch %d differs from the plain run" % i)
+                break
+        if not np.array_equal(outs_plain[0], outs["default"], equal_nan=True):
+            notes.append("device entry != host entry")
 
         # 2. alpha sweep in one call == rounds of set_alpha + apply (same bits), against the checker
         alphas = [float(a) for a in rng.choice([0.85, 0.9, 0.95, 1.0, 1.05, 1.1, 1.15], size=int(rng.integers(1, 5)), replace=False)]
