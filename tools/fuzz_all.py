@@ -24,6 +24,7 @@ orc = G.load_oracle()
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"   # wider ranges: band edges, warp, delta orders, filter / column counts, tiny shifts
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"     # many long utterances per plan (whole grids, the tail split, the 4-frame pieces): a sample of them is checked
 rng = np.random.default_rng(seed)
 LOW, HIGH_CUT = 64.0, 0.0
 
@@ -124,6 +125,8 @@ for case in range(n_cases):
         LOW, HIGH_CUT = float(rng.integers(0, 300)), float(rng.integers(0, int(sr / 8)))
     D = (l1 if dyn else 0) + (l2 if dyn == 2 else 0)
     frames = [max(int(x), 2 * D + 2) for x in rng.integers(2, 50, size=int(rng.integers(1, 6)))]
+    if BIG:
+        frames = [max(int(x), 2 * D + 2) for x in rng.integers(100, 1500, size=int(rng.integers(40, 300)))]
     lens = [(T - 1) * S + W + int(rng.integers(0, S)) for T in frames]
     odd_ok = ch == 1
     offs, pos = [], int(rng.integers(0, 3)) if odd_ok else 0
@@ -162,7 +165,9 @@ for case in range(n_cases):
             got = m.batch_run_host(pcm)
             name = m.dominant_kernel_name()
             cfg = mkcfg(ibs + Wo, nrm)
-            for u, n in enumerate(lens):
+            check = range(len(lens)) if not BIG else sorted(set([0, len(lens) - 1] + [int(x) for x in rng.integers(0, len(lens), size=6)]))
+            for u in check:
+                n = lens[u]
                 seg = pad(mono[offs[u]:offs[u] + n])
                 want = orc.run_utterance(cfg, seg, wo, alpha=alpha, bug_compat=False)
                 g = got[rows[u]:rows[u] + want.shape[0]]
