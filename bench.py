@@ -286,8 +286,19 @@ def measure_traffic_live(argv_tail, timeout_s=75):
             d = os.path.join(tmp, counter)
             cmd = [tool, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--settle-ms", "0", "--no-cpu-baseline"] + argv_tail
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
-            if r.returncode != 0:
+            # (its own process group: on a timeout the profiler AND the benchmark under it are killed, by exact group id)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                return None
+            if rc != 0:
                 return None
             rows = 0
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
