@@ -131,6 +131,7 @@ struct mfx_handle {
     size_t stage_tail_off = 0;  // samples: where the pending tail (h->remaining samples) starts in h_stage
     float *h_out_stage = nullptr;         // pinned staging of get_output_data (allocated on first use)
     size_t h_out_stage_n = 0;
+    bool rows_in_stage = false;           // the current block's rows were written straight into h_out_stage by the delta kernel
     hipEvent_t ev_copy[16] = {};          // chunk events of the pipelined device-to-host copy
     // VTLN sweep (mfx_apply_alphas): one filterbank, one static and one output block per alpha
     std::vector<float> sweep_alphas;      // alphas of the tables currently in d_sweep_w
@@ -1464,11 +1465,35 @@ int apply_impl(mfx_handle *h, const float *alphas, int n_alpha)
         if (rc != MFX_OK) return rc;
     }
 
+    // Small blocks (round 4): the delta kernel -- the last one that touches the rows unless they are normalised after the
+    // deltas -- writes them straight into the page-locked staging buffer (posted writes over the link, consecutive
+    // threads on consecutive addresses), and get_output_data has nothing to launch: one kernel and one launch less per
+    // call sequence (profiles/r04/stream_small_timeline.txt).  Same kernel, same values: the same bits as through d_blk.
+    h->rows_in_stage = false;
+    float *rows_out = d_blk;
+    // (not when the rows are normalised after the deltas: the one-launch normaliser is ONE block per segment, and a
+    // single CU writing 155 KB over the link takes what the copy kernel it would save takes -- measured, +- 0.5 us)
+    if (!sweep && !(norm && h->cfg.norm_after_dyn) && small_block(h, (size_t)wc * h->width * sizeof(float))) {
+        const size_t want = (size_t)h->cap_rows * h->width + 4;
+        if (h->h_out_stage_n < want) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            if (h->h_out_stage) (void)hipHostFree(h->h_out_stage);
+            h->h_out_stage = nullptr;
+            h->h_out_stage_n = 0;
+            HIP_TRY(h, hipHostMalloc((void **)&h->h_out_stage, want * sizeof(float), hipHostMallocDefault));
+            h->h_out_stage_n = want;
+        }
+        void *dev = nullptr;
+        if (is_pinned_host(h->h_out_stage, &dev) && dev) {
+            rows_out = (float *)dev;
+            h->rows_in_stage = true;
+        }
+    }
     DeltaParams dp;
     std::memset(&dp, 0, sizeof(dp));
     dp.src = d_src;
     dp.src_pitch = h->cols;
-    dp.out = d_blk;
+    dp.out = rows_out;
     dp.out_pitch = h->width;
     dp.segs = segs_out;
     dp.n_segs = n_tab;
@@ -1530,6 +1555,11 @@ extern "C" int mfx_get_output_data(mfx_handle *h, float *data_out, int32_t frame
     if (frames > h->cap_rows) return fail(h, MFX_ERR_WINDOW_HIGH, kMsgHigh);
     if (frames == 0) return MFX_OK;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->rows_in_stage && h->block_applied) { // the delta kernel wrote the rows into page-locked memory: wait for it, copy
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        std::memcpy(data_out, h->h_out_stage, (size_t)frames * h->width * sizeof(float));
+        return MFX_OK;
+    }
     return download_rows(h, data_out, h->d_blk.p, (size_t)frames * h->width);
 }
 
