@@ -4,6 +4,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <functional>
+#include <vector>
 
 namespace mfx {
 
@@ -102,6 +104,39 @@ void build_twiddles(int n, int count, std::vector<float> &t)
 
 namespace mfx {
 
+// Start bins for the filters of one round: cands[j] lists lane j's admissible starts (its own first, then earlier ones);
+// a start occupies residue (start / align) mod residues.  Returns one start per lane such that as many lanes as possible
+// hold a residue of their own (maximum bipartite matching, augmenting paths; lanes left over keep their own start).
+static std::vector<int> match_starts(const std::vector<std::vector<int>> &cands, int align, int residues)
+{
+    const int n = (int)cands.size();
+    std::vector<int> owner(residues, -1), choice(n, -1);
+    std::vector<char> seen;
+    auto res = [&](int start) { return (start / align) % residues; };
+    std::function<bool(int)> augment = [&](int j) {
+        for (size_t c = 0; c < cands[j].size(); ++c) {
+            const int q = res(cands[j][c]);
+            if (seen[q]) continue;
+            seen[q] = 1;
+            if (owner[q] < 0 || augment(owner[q])) {
+                owner[q] = j;
+                choice[j] = (int)c;
+                return true;
+            }
+        }
+        return false;
+    };
+    for (int j = 0; j < n; ++j) {
+        if (cands[j].empty()) continue;
+        seen.assign(residues, 0);
+        augment(j);
+    }
+    std::vector<int> pick(n, 0);
+    for (int j = 0; j < n; ++j)
+        if (!cands[j].empty()) pick[j] = cands[j][choice[j] < 0 ? 0 : choice[j]];
+    return pick;
+}
+
 static int stride_4odd(int n)
 {
     int q = (n + 3) / 4;
@@ -121,13 +156,11 @@ bool build_mel_lane_plan(const MelTable &t, int num_banks, int fft_size, int max
     out.fid.assign((size_t)16 * out.rounds, -1);
     int total = 0;
     for (int r = 0; r < out.rounds; ++r) {
-        // Starts are even (two bins per 8-byte LDS read).  The 16 lanes of a frame read at
-        // start + s simultaneously; they fall on distinct bank pairs when (start / 2) mod 16 differs
-        // from lane to lane, so a clashing filter begins up to a few pairs early (zero weights).
-        bool used[16] = {false};
-        int longest = 0;
-        // the round's length without any shift: a shift must not make the round longer (a two-way bank conflict costs
-        // one LDS cycle per read, a longer round a whole 8-bin trip on every lane)
+        // Starts are multiples of `align` bins (an 8- or 16-byte LDS read).  The 16 lanes of a frame read at start + s
+        // simultaneously; they fall on distinct bank groups when (start / align) mod 16 differs from lane to lane, so a
+        // clashing filter may begin a few reads early (zero weights: the sum keeps its bits) -- as long as the round does
+        // not get longer for it (a two-way bank conflict costs one LDS cycle per read, a longer round a whole 8-bin trip
+        // on every lane).  Which filter moves where is a maximum bipartite matching of the round's filters to residues.
         int natural = 8;
         for (int j = 0; j < 16; ++j) {
             const int idx = r * 16 + j;
@@ -135,24 +168,26 @@ bool build_mel_lane_plan(const MelTable &t, int num_banks, int fft_size, int max
             const int m = order[idx];
             natural = std::max(natural, (t.beg[m + 2] - (t.beg[m] & ~(align - 1)) + 7) & ~7);
         }
+        std::vector<std::vector<int>> cands(16);
         for (int j = 0; j < 16; ++j) {
             const int idx = r * 16 + j;
             if (idx >= num_banks) continue;
             const int m = order[idx];
-            const int b0 = t.beg[m], b1 = t.beg[m + 2];
-            int start = b0 & ~(align - 1);
-            for (int d = 0; d < 4; ++d) {
-                const int cand = (b0 & ~(align - 1)) - align * d;
-                if (cand < 0 || b1 - cand > natural) break;
-                if (!used[(cand / align) & 15]) {
-                    start = cand;
-                    break;
-                }
+            for (int d = 0; d < 16; ++d) {
+                const int cand = (t.beg[m] & ~(align - 1)) - align * d;
+                if (cand < 0 || t.beg[m + 2] - cand > natural) break;
+                cands[j].push_back(cand);
             }
-            used[(start / align) & 15] = true;
-            out.start[r * 16 + j] = start;
+        }
+        const std::vector<int> pick = match_starts(cands, align, 16);
+        int longest = 0;
+        for (int j = 0; j < 16; ++j) {
+            const int idx = r * 16 + j;
+            if (idx >= num_banks) continue;
+            const int m = order[idx];
+            out.start[r * 16 + j] = pick[j];
             out.fid[r * 16 + j] = m;
-            longest = std::max(longest, b1 - start);
+            longest = std::max(longest, t.beg[m + 2] - pick[j]);
         }
         out.L[r] = std::max(8, (longest + 7) & ~7);
         total += out.L[r];
@@ -188,28 +223,38 @@ bool build_mel_wave_plan(const MelTable &t, int num_banks, int fft_size, int max
     out.fid.assign((size_t)lanes * out.rounds, -1);
     int total = 0;
     for (int r = 0; r < out.rounds; ++r) {
-        // An 8-byte read is served in two groups of 32 lanes over 32 bank pairs: a group is conflict free when
-        // (start / 2) mod 32 differs from lane to lane, so a clashing filter begins a few pairs early (zero weights).
-        bool used[2][32] = {{false}};
-        int longest = 0;
+        // An 8-byte read is served in groups of 32 lanes over 32 bank pairs: a group is conflict free when
+        // (start / 2) mod 32 differs from lane to lane, so a clashing filter begins a few pairs early (zero weights) where
+        // the round does not get longer for it; the assignment is a maximum matching per group of 32 lanes.
+        int natural = 8;
         for (int j = 0; j < lanes; ++j) {
             const int idx = r * lanes + j;
             if (idx >= num_banks) continue;
             const int m = order[idx];
-            const int b0 = t.beg[m], b1 = t.beg[m + 2];
-            int start = b0 & ~1;
-            for (int d = 0; d < 6; ++d) {
-                const int cand = (b0 & ~1) - 2 * d;
-                if (cand < 0) break;
-                if (!used[j >> 5][(cand >> 1) & 31]) {
-                    start = cand;
-                    break;
+            natural = std::max(natural, (t.beg[m + 2] - (t.beg[m] & ~1) + 7) & ~7);
+        }
+        int longest = 0;
+        for (int g0 = 0; g0 < lanes; g0 += 32) {
+            std::vector<std::vector<int>> cands(32);
+            for (int j = g0; j < g0 + 32; ++j) {
+                const int idx = r * lanes + j;
+                if (idx >= num_banks) continue;
+                const int m = order[idx];
+                for (int d = 0; d < 32; ++d) {
+                    const int cand = (t.beg[m] & ~1) - 2 * d;
+                    if (cand < 0 || t.beg[m + 2] - cand > natural) break;
+                    cands[j - g0].push_back(cand);
                 }
             }
-            used[j >> 5][(start >> 1) & 31] = true;
-            out.start[r * lanes + j] = start;
-            out.fid[r * lanes + j] = m;
-            longest = std::max(longest, b1 - start);
+            const std::vector<int> pick = match_starts(cands, 2, 32);
+            for (int j = g0; j < g0 + 32; ++j) {
+                const int idx = r * lanes + j;
+                if (idx >= num_banks) continue;
+                const int m = order[idx];
+                out.start[r * lanes + j] = pick[j - g0];
+                out.fid[r * lanes + j] = m;
+                longest = std::max(longest, t.beg[m + 2] - pick[j - g0]);
+            }
         }
         out.L[r] = std::max(8, (longest + 7) & ~7);
         total += out.L[r];

@@ -133,6 +133,50 @@ def test_mel_lane_plan_walks_every_filter_once(pkg, lanes, nb, W2, sr, alpha, ma
     assert not pl["w"][:, base:].any()
 
 
+@pytest.mark.parametrize("lanes,nb,W2,sr,max_read,clashes", [
+    (16, 40, 512, 16000.0, 479, 0), (16, 26, 512, 16000.0, 479, 0), (16, 15, 512, 16000.0, 479, 0),
+    (16, 80, 1024, 16000.0, 527, 10), (32, 128, 2048, 44100.0, 1039, 6), (64, 40, 512, 16000.0, 511, None)])
+def test_mel_lane_plan_starts_are_a_maximum_matching(pkg, lanes, nb, W2, sr, max_read, clashes):
+    """The lanes of one LDS access group (16 lanes of a frame / 32 lanes of a wave half) read magnitudes at start + s together:
+    they are conflict free when (start / align) mod group differs from lane to lane.  A filter may start early on zero
+    weights as long as its round does not grow; the builder picks the starts by a maximum bipartite matching, so no other
+    choice of early starts leaves fewer lanes sharing a residue (checked here against an independent matching), and the
+    headline shapes are clash free (C2, C1, R) or down to the short last rounds whose filters have nowhere to move."""
+    wt, beg = pkg.host_mel_table(nb, W2, sr, 64.0, sr / 2, 1.0)
+    pl = pkg.host_mel_lane_plan(lanes, wt, beg, max_read)
+    align = 4 if (lanes == 16 and W2 == 1024) else 2
+    group = 16 if lanes == 16 else 32
+    total = 0
+    for r in range(pl["rounds"]):
+        for g0 in range(0, lanes, group):
+            js = [j for j in range(g0, min(g0 + group, lanes)) if pl["fid"][r, j] >= 0]
+            if not js:
+                continue
+            L = int(pl["L"][r])
+            have = len(js) - len({(int(pl["start"][r, j]) // align) % group for j in js})
+            cands = []
+            for j in js:
+                m = int(pl["fid"][r, j])
+                b0, b1 = int(beg[m]) & ~(align - 1), int(beg[m + 2])
+                cands.append([(c // align) % group for c in range(b0, -1, -align) if b1 - c <= L])
+            owner = {}
+
+            def augment(i, seen):
+                for q in cands[i]:
+                    if q in seen:
+                        continue
+                    seen.add(q)
+                    if q not in owner or augment(owner[q], seen):
+                        owner[q] = i
+                        return True
+                return False
+            best = len(js) - sum(augment(i, set()) for i in range(len(js)))
+            assert have == best, (r, g0, have, best)
+            total += have
+    if clashes is not None:
+        assert total == clashes
+
+
 @pytest.mark.parametrize("nb,nc,c0", [(40, 13, False), (26, 13, False), (15, 12, True), (80, 13, False), (128, 40, False)])
 def test_dct_mfma_operands_are_the_matrix(pkg, nb, nc, c0):
     """Operand table of the DCT on the matrix pipe: lane (k = lane >> 4, n = lane & 15) of K step j of tile t holds
