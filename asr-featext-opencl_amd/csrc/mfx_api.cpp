@@ -1917,7 +1917,7 @@ int batch_run_range(mfx_handle *h, const int16_t *d_pcm, int64_t pcm_samples_tot
         HIP_TRY(h, launch_front512(p, /*to_spectrum=*/false, h->batch_aligned, h->nm16, h->stream));
     } else if (fused1024) {
         ProfScope ps(h);
-        HIP_TRY(h, launch_front1024(p, h->batch_aligned, h->nm16, h->stream));
+        HIP_TRY(h, launch_front1024(p, h->batch_aligned, h->nm16, h->stream, (h->cfg.engine & MFX_ENGINE_FRONT1024_12_WAVES) ? 12 : 16));
     } else if (fused2048) {
         p.spec = h->d_spec.p; // unused by the fused kernel; a -DMFX_STAMPS dev build drops its cycle sums here
         ProfScope ps(h);

@@ -718,17 +718,21 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
 // each per 8-byte read and adds them in ascending bin order (mfcccpu.cpp:192-220); log, DCT on the matrix pipe as in
 // k_front512 (20 K steps: at most 80 filters).
 // ------------------------------------------------------------------------------------------------
-constexpr int kWavesL = 12;       // waves per block = per CU (3 per SIMD: 168 registers)
-constexpr int kSlotL = 672;       // dwords per frame slot: [0, 512) transposes, then E | O magnitudes (2 x 264); log energies
-                                  // from 528 (672 = 32 mod 64: neighbouring slots sit on complementary bank halves)
+constexpr int kSlotL = 544;       // dwords per frame slot: E magnitudes [0, 264) | O magnitudes [264, 528).  Phase E transposes through
+                                  // [0, 512) before any magnitude lands; phase O, with the E magnitudes in place, through
+                                  // [272, 528) one component at a time; the log energies overlay the E magnitudes once the mel
+                                  // walk is over (544 = 32 mod 64: neighbouring slots sit on complementary bank halves)
 constexpr int kOddOffL = 264;     // O magnitudes inside the slot
-constexpr int kMelOffL = 528;
+constexpr int kTrOffL = 272;      // phase O's transposition (256 dwords)
+constexpr int kMelOffL = 0;       // log energies (frame `slot` staggered by 8 slot words)
 constexpr int kTabStrideO = 68;   // dwords per lane row of the phase-O window table (16 x (A, B, C, D) + pad: 17 16-byte words)
 constexpr int kDctStepsL = 20;    // num_banks <= 80
 constexpr int kDctRowL = 20;      // dwords per lane row of the B operand table (5 16-byte words: odd)
 
-template <bool ALIGNED, int NM>
-__global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
+// WAVES per block = per CU: 16 (4 per SIMD, 128 registers: the aligned builds of windows up to 512 samples, when the tables
+// leave room for 16 x 4 slots) or 12 (3 per SIMD, 168 registers: every other build)
+template <bool ALIGNED, int NM, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, WAVES / 4) k_front1024(FrontParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -747,25 +751,25 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
     float *s_dct = (float *)(s_mmeta + 32 * rounds);   // [64][kDctRowL]: matrix-pipe B operands per lane
     float *s_wave = s_dct + 64 * kDctRowL + wave * (4 * kSlotL);
     float *xb = s_wave + slot * kSlotL;
-    int *s_ctr = (int *)(s_dct + 64 * kDctRowL + kWavesL * (4 * kSlotL));
+    int *s_ctr = (int *)(s_dct + 64 * kDctRowL + WAVES * (4 * kSlotL));
     if (tid == 0) *s_ctr = 0;
 
-    for (int i = tid; i < 256; i += kWavesL * 64) { // HBM tables are [lane][m]
+    for (int i = tid; i < 256; i += WAVES * 64) { // HBM tables are [lane][m]
         ((float2 *)(s_win + (i >> 4) * kTabStride))[i & 15] = ((const float2 *)p.winpair)[i];
         ((float4 *)(s_winO + (i >> 4) * kTabStrideO))[i & 15] = ((const float4 *)p.win1024o)[i];
         ((float2 *)(s_tw + (i >> 4) * kTabStride))[i & 15] = ((const float2 *)p.twid_pass)[i];
     }
-    for (int i = tid; i < 128; i += kWavesL * 64) { // twid_split holds -i W_1024^e, e <= 512, in natural order
+    for (int i = tid; i < 128; i += WAVES * 64) { // twid_split holds -i W_1024^e, e <= 512, in natural order
         ((float2 *)(s_splitE + (i & 15) * kSplitStride))[i >> 4] = ((const float2 *)p.twid_split)[2 * i];
         ((float2 *)(s_splitO + (i & 15) * kSplitStride))[i >> 4] = ((const float2 *)p.twid_split)[2 * i + 1];
     }
-    for (int i = tid; i < 16 * RS; i += kWavesL * 64) s_melw[i] = p.mel_lane_w[i];
-    for (int i = tid; i < 16 * rounds; i += kWavesL * 64) {
+    for (int i = tid; i < 16 * RS; i += WAVES * 64) s_melw[i] = p.mel_lane_w[i];
+    for (int i = tid; i < 16 * rounds; i += WAVES * 64) {
         s_mmeta[2 * i] = p.mel_lane_start[i] >> 1; // (index into the even / odd magnitude arrays)
         const int fid = p.mel_lane_fid[i];
         s_mmeta[2 * i + 1] = fid < 0 ? 4 * kDctStepsL : fid; // idle lanes park their value in a word nobody reads
     }
-    for (int i = tid; i < 64 * kDctRowL; i += kWavesL * 64) {
+    for (int i = tid; i < 64 * kDctRowL; i += WAVES * 64) {
         // (MFX_DCT_QUARTERS: B operand of band 20 kb + j on lane (kb = lane >> 4, n = lane & 15); see k_front512)
         const int ln = i / kDctRowL, j = i - ln * kDctRowL, n = ln & 15;
         const int m = MFX_DCT_QUARTERS ? kDctStepsL * (ln >> 4) + j : 4 * j + (ln >> 4);
@@ -843,36 +847,27 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
                 pcm_issue<ALIGNED, NM>(cur, last ? cnxt.rsrc : ccur.rsrc, last ? lane_off(cnxt, slot) : lane_off(ccur, f + 4));
             }
             // sample pair m of this lane (n = l + 16 m) as two floats
-            auto pair_of = [&](int m, float &x0, float &x1) {
-                const uint32_t d = ALIGNED ? cur.d[m] : dd[m];
+            // (`fresh`: the second phase re-reads the raw word opaquely and converts it again -- 26 floats kept alive across a
+            // phase cost more registers than the conversions cost issue slots)
+            auto pair_of = [&](int m, float &x0, float &x1, bool fresh) {
+                uint32_t d = ALIGNED ? cur.d[m] : dd[m];
+                if (fresh) asm volatile("" : "+v"(d));
                 x0 = (float)(int)(short)(d & 0xffffu);
                 x1 = (float)((int)d >> 16);
             };
-            // pass A + inter-pass twiddle + 16 x 16 transpose through the slot + pass B: a[pp] = FFT256(a)[l + 16 pp]
-            auto fft256 = [&](float2(&a)[16]) {
+            // pass A + inter-pass twiddles of the 256-point transform; the 16 x 16 transposition through the slot and pass B
+            // follow in each phase (a[pp] = FFT256(a)[l + 16 pp] after them)
+            auto fft256_head = [&](float2(&a)[16]) {
                 fft16(a);
-                {
-                    float4 tq[8];
+                float4 tq[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) tq[k] = lds_read_b128((const float4 *)(s_tw + l * kTabStride) + k);
+                for (int k = 0; k < 8; ++k) tq[k] = lds_read_b128((const float4 *)(s_tw + l * kTabStride) + k);
 #pragma unroll
-                    for (int k = 0; k < 16; k += 2) {
-                        const float4 t = tq[k >> 1];
-                        if (k > 0) a[k] = cmul(a[k], make_float2(t.x, t.y));
-                        a[k + 1] = cmul(a[k + 1], make_float2(t.z, t.w));
-                    }
+                for (int k = 0; k < 16; k += 2) {
+                    const float4 t = tq[k >> 1];
+                    if (k > 0) a[k] = cmul(a[k], make_float2(t.x, t.y));
+                    a[k + 1] = cmul(a[k + 1], make_float2(t.z, t.w));
                 }
-#pragma unroll
-                for (int k = 0; k < 16; ++k) ((float2 *)(xb + k * 32))[l ^ (k & 14)] = a[k];
-                wave_sync();
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float4 v = ((const float4 *)(xb + l * 32))[j ^ (l >> 1)];
-                    a[2 * j] = make_float2(v.x, v.y);
-                    a[2 * j + 1] = make_float2(v.z, v.w);
-                }
-                wave_sync();
-                fft16(a);
             };
 
             // NM > 16 (a window longer than 512 samples, aligned frames only): the second half of the frame folds onto the
@@ -896,27 +891,115 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
                 return r;
             };
 
-            // ---- phase O: odd bins
-            float magO_k[8], magO_p[8];
+            // ---- phase E: even bins = k_front512's transform of the same samples; the magnitudes go straight to the slot
+            // (E[i] = |X[2 i]|, i <= 256: the transposition's words are consumed by then)
+            {
+                float2 a[16];
+                constexpr int NW = FULL ? 1 : (NM + 1) / 2;
+                float4 wq[NW];
+                if (!FULL) {
+#pragma unroll
+                    for (int m = 0; m < NW; ++m) wq[m] = ((const float4 *)(s_win + l * kTabStride))[m];
+                }
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    if (FULL) {
+                        a[m] = folded(m, true, false);
+                    } else if (m < NM) {
+                        float x0, x1;
+                        pair_of(m, x0, x1, false);
+                        const float2 w = (m & 1) ? make_float2(wq[m >> 1].z, wq[m >> 1].w) : make_float2(wq[m >> 1].x, wq[m >> 1].y);
+                        a[m] = make_float2(w.x * x0, w.y * x1);
+                    } else {
+                        a[m] = make_float2(0.f, 0.f);
+                    }
+                }
+                fft256_head(a);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) ((float2 *)(xb + k * 32))[l ^ (k & 14)] = a[k];
+                wave_sync();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 v = ((const float4 *)(xb + l * 32))[j ^ (l >> 1)];
+                    a[2 * j] = make_float2(v.x, v.y);
+                    a[2 * j + 1] = make_float2(v.z, v.w);
+                }
+                wave_sync();
+                fft16(a);
+                const float m128r = a[8].x + a[8].x, m128i = a[8].y + a[8].y;
+                if (l == 0) xb[128] = __builtin_amdgcn_sqrtf(m128r * m128r + m128i * m128i);
+                float4 csq[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) csq[j] = ((const float4 *)(s_splitE + l * kSplitStride))[j];
+                float *elo = xb + l, *ehi = xb + (144 - l); // i = l + 16 p and 256 - l - 16 p
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) {
+                    const float zr = row_partner_own0(a[(16 - pp) & 15].x, a[15 - pp].x);
+                    const float zi = row_partner_own0(a[(16 - pp) & 15].y, a[15 - pp].y);
+                    const float2 cs = (pp & 1) ? make_float2(csq[pp >> 1].z, csq[pp >> 1].w) : make_float2(csq[pp >> 1].x, csq[pp >> 1].y);
+                    const float sr = a[pp].x + zr, si = a[pp].y - zi;
+                    const float dr = a[pp].x - zr, di = a[pp].y + zi;
+                    const float tr = cs.x * dr - cs.y * di;
+                    const float ti = cs.x * di + cs.y * dr;
+                    const float xr = sr + tr, xi = si + ti;
+                    const float yr = sr - tr, yi = si - ti;
+                    elo[16 * pp] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi); // the window taps carry 0.5 / W2
+                    ehi[16 * (7 - pp)] = __builtin_amdgcn_sqrtf(yr * yr + yi * yi);
+                }
+            }
+
+            // ---- phase O: odd bins.  The E magnitudes already sit in [0, 264) of the slot, so this transposition goes through
+            // [kTrOffL, kTrOffL + 256) one component at a time: word (row k, column c) of a component at 16 k + (c ^ 4 (k >> 2))
+            // (4-byte stores of a row land on 16 consecutive banks; the 16-byte reads of rows l fall on distinct bank quads)
             {
                 float2 a[16];
 #pragma unroll
                 for (int m = 0; m < 16; ++m) {
                     if (FULL) {
-                        a[m] = cmul(folded(m, false, false), ((const float2 *)(s_win + l * kTabStride))[m]); // x W_512^(l + 16 m)
+                        a[m] = cmul(folded(m, false, true), ((const float2 *)(s_win + l * kTabStride))[m]); // x W_512^(l + 16 m)
                     } else if (m < NM) {
                         float x0, x1;
-                        pair_of(m, x0, x1);
+                        pair_of(m, x0, x1, true);
                         const float4 t = ((const float4 *)(s_winO + l * kTabStrideO))[m];
                         a[m] = make_float2(t.x * x0 + t.y * x1, t.z * x0 + t.w * x1);
                     } else {
                         a[m] = make_float2(0.f, 0.f);
                     }
                 }
-                fft256(a);
+                // the raw words are consumed: prefetch the next 4 frames (of this chunk, or the first of the next chunk)
+                if (ALIGNED) pcm_issue<ALIGNED, NM>(cur, last ? cnxt.rsrc : ccur.rsrc, last ? lane_off(cnxt, slot) : lane_off(ccur, f + 4));
+                fft256_head(a);
+                float *xt = xb + kTrOffL;
+                const float4 *xrow = (const float4 *)(xt + l * 16);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) xt[k * 16 + (l ^ (4 * (k >> 2)))] = a[k].x;
+                wave_sync();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 v = xrow[j ^ (l >> 2)];
+                    a[4 * j].x = v.x;
+                    a[4 * j + 1].x = v.y;
+                    a[4 * j + 2].x = v.z;
+                    a[4 * j + 3].x = v.w;
+                }
+                wave_sync();
+#pragma unroll
+                for (int k = 0; k < 16; ++k) xt[k * 16 + (l ^ (4 * (k >> 2)))] = a[k].y;
+                wave_sync();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 v = xrow[j ^ (l >> 2)];
+                    a[4 * j].y = v.x;
+                    a[4 * j + 1].y = v.y;
+                    a[4 * j + 2].y = v.z;
+                    a[4 * j + 3].y = v.w;
+                }
+                wave_sync();
+                fft16(a);
                 float4 csq[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) csq[j] = ((const float4 *)(s_splitO + l * kSplitStride))[j];
+                float *olo = xb + kOddOffL + l, *ohi = xb + kOddOffL + (143 - l); // O[i] = |X[2 i + 1]|: i = l + 16 p and 255 - l - 16 p
 #pragma unroll
                 for (int pp = 0; pp < 8; ++pp) {
                     // partner V[255 - k]: register 15 - pp of lane 15 - l
@@ -929,108 +1012,54 @@ __global__ void __launch_bounds__(kWavesL * 64, 3) k_front1024(FrontParams p)
                     const float ti = cs.x * di + cs.y * dr;
                     const float xr = sr + tr, xi = si + ti;
                     const float yr = sr - tr, yi = si - ti;
-                    magO_k[pp] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi); // the window taps carry 0.5 / W2
-                    magO_p[pp] = __builtin_amdgcn_sqrtf(yr * yr + yi * yi);
+                    olo[16 * pp] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
+                    ohi[16 * (7 - pp)] = __builtin_amdgcn_sqrtf(yr * yr + yi * yi);
                 }
-            }
-
-            // ---- phase E: even bins = k_front512's transform of the same samples
-            float magE_k[8], magE_p[8], magE128;
-            {
-                float2 a[16];
-                constexpr int NW = FULL ? 1 : (NM + 1) / 2;
-                float4 wq[NW];
-                if (!FULL) {
-#pragma unroll
-                    for (int m = 0; m < NW; ++m) wq[m] = ((const float4 *)(s_win + l * kTabStride))[m];
-                }
-#pragma unroll
-                for (int m = 0; m < 16; ++m) {
-                    if (FULL) {
-                        a[m] = folded(m, true, true);
-                    } else if (m < NM) {
-                        float x0, x1;
-                        pair_of(m, x0, x1);
-                        const float2 w = (m & 1) ? make_float2(wq[m >> 1].z, wq[m >> 1].w) : make_float2(wq[m >> 1].x, wq[m >> 1].y);
-                        a[m] = make_float2(w.x * x0, w.y * x1);
-                    } else {
-                        a[m] = make_float2(0.f, 0.f);
-                    }
-                }
-                // the raw words are consumed: prefetch the next 4 frames (of this chunk, or the first of the next chunk)
-                if (ALIGNED) pcm_issue<ALIGNED, NM>(cur, last ? cnxt.rsrc : ccur.rsrc, last ? lane_off(cnxt, slot) : lane_off(ccur, f + 4));
-                fft256(a);
-                const float m128r = a[8].x + a[8].x, m128i = a[8].y + a[8].y;
-                magE128 = __builtin_amdgcn_sqrtf(m128r * m128r + m128i * m128i);
-                float4 csq[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) csq[j] = ((const float4 *)(s_splitE + l * kSplitStride))[j];
-#pragma unroll
-                for (int pp = 0; pp < 8; ++pp) {
-                    const float zr = row_partner_own0(a[(16 - pp) & 15].x, a[15 - pp].x);
-                    const float zi = row_partner_own0(a[(16 - pp) & 15].y, a[15 - pp].y);
-                    const float2 cs = (pp & 1) ? make_float2(csq[pp >> 1].z, csq[pp >> 1].w) : make_float2(csq[pp >> 1].x, csq[pp >> 1].y);
-                    const float sr = a[pp].x + zr, si = a[pp].y - zi;
-                    const float dr = a[pp].x - zr, di = a[pp].y + zi;
-                    const float tr = cs.x * dr - cs.y * di;
-                    const float ti = cs.x * di + cs.y * dr;
-                    const float xr = sr + tr, xi = si + ti;
-                    const float yr = sr - tr, yi = si - ti;
-                    magE_k[pp] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
-                    magE_p[pp] = __builtin_amdgcn_sqrtf(yr * yr + yi * yi);
-                }
-            }
-
-            // ---- magnitudes to the slot: E[i] = |X[2 i]|, i <= 256; O[i] = |X[2 i + 1]|, i < 256
-            {
-                float *elo = xb + l, *ehi = xb + (144 - l);                        // i = l + 16 p and 256 - l - 16 p
-                float *olo = xb + kOddOffL + l, *ohi = xb + kOddOffL + (143 - l);   // i = l + 16 p and 255 - l - 16 p
-#pragma unroll
-                for (int pp = 0; pp < 8; ++pp) elo[16 * pp] = magE_k[pp];
-#pragma unroll
-                for (int pp = 0; pp < 8; ++pp) ehi[16 * pp] = magE_p[7 - pp];
-                if (l == 0) xb[128] = magE128;
-#pragma unroll
-                for (int pp = 0; pp < 8; ++pp) olo[16 * pp] = magO_k[pp];
-#pragma unroll
-                for (int pp = 0; pp < 8; ++pp) ohi[16 * pp] = magO_p[7 - pp];
             }
             wave_sync();
 
             // ---- mel filterbank: per round every lane walks one filter's bins in ascending order
-            // (mfcccpu.cpp:192-220); starts are multiples of 4 bins: two even and two odd bins per 8-byte read
+            // (mfcccpu.cpp:192-220); starts are multiples of 4 bins: two even and two odd bins per 8-byte read.  The log
+            // energies wait in registers (at most 5 rounds) and overlay the magnitudes once every lane has finished reading.
             const float *wrow = s_melw + l * RS;
             float *dst = p.feat + (out_row + f0) * (int64_t)p.feat_pitch + slot * p.feat_pitch;
             float *lm = xb + kMelOffL + 8 * slot;
             const int2 *mmeta = (const int2 *)s_mmeta + l;
-            for (int r = 0; r < rounds; ++r) {
-                const int L = p.mel_L[r];
-                const int2 mt = *mmeta;
-                mmeta += 16;
-                const float *me = xb + mt.x, *mo = xb + kOddOffL + mt.x;
-                const int fid = mt.y;
-                float acc = 0.f;
-                for (int s = 0; s < L; s += 8) {
-                    float4 w[2];
-                    float2 e[2], o[2];
+            float le[kDctStepsL / 4];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) w[q] = *(const float4 *)(wrow + s + 4 * q);
+            for (int r = 0; r < kDctStepsL / 4; ++r) {
+                le[r] = 0.f;
+                if (r < rounds) {
+                    const int L = p.mel_L[r];
+                    const int first = mmeta[16 * r].x;
+                    const float *me = xb + first, *mo = xb + kOddOffL + first;
+                    float acc = 0.f;
+                    for (int s = 0; s < L; s += 8) {
+                        float4 w[2];
+                        float2 e[2], o[2];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        e[q] = lds_read_b64((const float2 *)(me + (s >> 1) + 2 * q));
-                        o[q] = lds_read_b64((const float2 *)(mo + (s >> 1) + 2 * q));
+                        for (int q = 0; q < 2; ++q) w[q] = *(const float4 *)(wrow + s + 4 * q);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            e[q] = lds_read_b64((const float2 *)(me + (s >> 1) + 2 * q));
+                            o[q] = lds_read_b64((const float2 *)(mo + (s >> 1) + 2 * q));
+                        }
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            acc += w[q].x * e[q].x;
+                            acc += w[q].y * o[q].x;
+                            acc += w[q].z * e[q].y;
+                            acc += w[q].w * o[q].y;
+                        }
                     }
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        acc += w[q].x * e[q].x;
-                        acc += w[q].y * o[q].x;
-                        acc += w[q].z * e[q].y;
-                        acc += w[q].w * o[q].y;
-                    }
+                    wrow += L;
+                    le[r] = MFX_LOG(fmaxf(acc, 1e-30f));
                 }
-                wrow += L;
-                lm[fid] = MFX_LOG(fmaxf(acc, 1e-30f)); // (idle lanes: fid names a word nobody reads)
             }
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < kDctStepsL / 4; ++r)
+                if (r < rounds) lm[mmeta[16 * r].y] = le[r]; // (idle lanes: the filter id names a word nobody reads)
             wave_sync();
             if (!p.dct) {
                 // no DCT (ceps_len = 0: filterbank features, up to 80 log mel energies per frame): the frame's row as it is
@@ -1162,12 +1191,12 @@ hipError_t launch512(const FrontParams &p_in, hipStream_t stream)
 
 } // namespace
 
-size_t front1024_lds_bytes(const FrontParams &p)
+size_t front1024_lds_bytes(const FrontParams &p, int waves)
 {
     size_t f = 2 * 16 * kTabStride + 16 * kTabStrideO + 2 * 16 * kSplitStride; // window pairs (E, O), pass twiddles, split twiddles (E, O)
     f += (size_t)16 * p.mel_row_stride + (size_t)32 * p.mel_rounds;             // per-lane mel weights, bin starts + filter ids
     f += (size_t)64 * kDctRowL;                                                 // matrix-pipe operands of the DCT
-    f += (size_t)kWavesL * 4 * kSlotL + 4;                                      // 4 frame slots per wave, work counter
+    f += (size_t)waves * 4 * kSlotL + 4;                                        // 4 frame slots per wave, work counter
     return f * sizeof(float);
 }
 
@@ -1180,32 +1209,38 @@ bool front1024_supported(int fft_size, int window_size, int num_banks, int cols,
 }
 
 namespace {
-template <bool A, int NM>
+template <bool A, int NM, int WAVES>
 hipError_t launch1024(const FrontParams &p, hipStream_t stream)
 {
-    const size_t lds = front1024_lds_bytes(p);
+    const size_t lds = front1024_lds_bytes(p, WAVES);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_front1024<A, NM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_front1024<A, NM, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    int blocks = (p.n_chunks + kWavesL - 1) / kWavesL;
-    if (blocks > num_cus()) blocks = num_cus(); // one block of 12 waves per CU
+    int blocks = (p.n_chunks + WAVES - 1) / WAVES;
+    if (blocks > num_cus()) blocks = num_cus(); // one block per CU
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_front1024<A, NM>), dim3(blocks), dim3(kWavesL * 64), lds, stream, p);
+    hipLaunchKernelGGL((k_front1024<A, NM, WAVES>), dim3(blocks), dim3(WAVES * 64), lds, stream, p);
     return hipGetLastError();
 }
 } // namespace
 
-hipError_t launch_front1024(const FrontParams &p, bool aligned, int nm16, hipStream_t stream)
+int front1024_waves(const FrontParams &p, bool aligned, int nm16, int max_waves)
+{
+    return max_waves >= 16 && aligned && nm16 <= 16 && front1024_lds_bytes(p, 16) <= (size_t)160 * 1024 ? 16 : 12;
+}
+
+hipError_t launch_front1024(const FrontParams &p, bool aligned, int nm16, hipStream_t stream, int max_waves)
 {
     if (p.n_chunks <= 0) return hipSuccess;
     if (nm16 > 16) { // NM = rows of 16 sample pairs that carry window taps: 24 covers W <= 768, 32 the full 1024
         if (!aligned) return hipErrorInvalidValue;
-        return nm16 <= 24 ? launch1024<true, 24>(p, stream) : launch1024<true, 32>(p, stream);
+        return nm16 <= 24 ? launch1024<true, 24, 12>(p, stream) : launch1024<true, 32, 12>(p, stream);
     }
     const bool nm13 = nm16 <= 13;
-    if (aligned) return nm13 ? launch1024<true, 13>(p, stream) : launch1024<true, 16>(p, stream);
-    return nm13 ? launch1024<false, 13>(p, stream) : launch1024<false, 16>(p, stream);
+    if (front1024_waves(p, aligned, nm16, max_waves) == 16) return nm13 ? launch1024<true, 13, 16>(p, stream) : launch1024<true, 16, 16>(p, stream);
+    if (aligned) return nm13 ? launch1024<true, 13, 12>(p, stream) : launch1024<true, 16, 12>(p, stream);
+    return nm13 ? launch1024<false, 13, 12>(p, stream) : launch1024<false, 16, 12>(p, stream);
 }
 
 bool front512_supported(int fft_size, int window_size, int num_banks, int cols, int channels)

@@ -211,8 +211,9 @@ bool front512_supported(int fft_size, int window_size, int num_banks, int cols, 
 // k_front1024: 1024-point transform of a window of at most 512 samples on the k_front512 core (two 256-point complex
 // transforms per frame: even and odd bins), mel -> log -> DCT fused, statics out
 bool front1024_supported(int fft_size, int window_size, int num_banks, int cols, int channels, int ceps_len);
-size_t front1024_lds_bytes(const FrontParams &p);
-hipError_t launch_front1024(const FrontParams &p, bool aligned, int nm16, hipStream_t stream);
+size_t front1024_lds_bytes(const FrontParams &p, int waves = 12);
+int front1024_waves(const FrontParams &p, bool aligned, int nm16, int max_waves = 16); // 16 waves per CU where the build and the LDS allow, else 12
+hipError_t launch_front1024(const FrontParams &p, bool aligned, int nm16, hipStream_t stream, int max_waves = 16);
 
 // k_front2048 (mfx_front2048.hip): 2048-point transform of a window of at most 1152 samples, two frames per wave (32 lanes
 // each, 32 x 32 two-pass FFT), mono (aligned sample pairs) or interleaved stereo, mel -> log -> DCT fused, statics out

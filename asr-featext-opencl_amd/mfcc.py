@@ -270,7 +270,7 @@ KERNEL_TABLE = (
 
 
 ENGINE_NO_FRONT1024, ENGINE_FUSE_DELTA, ENGINE_NO_FRONT2048, ENGINE_STREAM_KERNELS, ENGINE_NORM_TWO_KERNELS = 1, 2, 4, 8, 16
-ENGINE_DMA_SMALL_BLOCKS, ENGINE_NO_DCT_SPLIT, ENGINE_NO_STUFF256 = 32, 64, 128     # mfx_config.engine bits (include/mfx.h)
+ENGINE_DMA_SMALL_BLOCKS, ENGINE_NO_DCT_SPLIT, ENGINE_NO_STUFF256, ENGINE_FRONT1024_12_WAVES = 32, 64, 128, 256     # mfx_config.engine bits (include/mfx.h)
 
 
 class MfccHip:

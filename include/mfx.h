@@ -106,6 +106,9 @@ typedef struct mfx_config {
 #define MFX_ENGINE_NO_STUFF256 128      /* 256-point transforms stay on the one-wave-per-frame kernel instead of the zero-stuffed
                                            form of the 512-point kernel                                                   */
 
+#define MFX_ENGINE_FRONT1024_12_WAVES 256 /* 1024-point fused kernel: the 12-waves-per-CU build also where the 16-wave build fits
+                                            (aligned frames, window <= 512 samples, tables small enough): the same bits      */
+
 typedef struct mfx_handle mfx_handle;
 
 /* ---- lifetime: replaces `new MfccOpenCL(..., cl_device_id)` (ASR_OCL.cpp:140-143,

@@ -486,6 +486,14 @@ def test_front1024_configurations(pkg, orc, W, S, nb, nc, c0, dyn, alpha):
     m2.batch_plan(offs, lens)
     g = groups_of(dyn)
     assert_close(got, m2.batch_run_host(pcm), "k_front1024 vs k_front_reg", groups=g)
+    # the kernel's two builds -- 16 waves per CU (aligned frames, windows up to 512 samples) and 12 (everything else, or on
+    # request: MFX_ENGINE_FRONT1024_12_WAVES) -- are the same arithmetic: the same bits
+    m3, _, _ = make_pair(pkg, orc, max(lens) + 2000, engine=pkg.mfcc.ENGINE_FRONT1024_12_WAVES, **kw)
+    if alpha != 1.0:
+        m3.set_alpha(alpha)
+    m3.batch_plan(offs, lens)
+    assert m3.dominant_kernel_name() == m.dominant_kernel_name()
+    assert np.array_equal(got, m3.batch_run_host(pcm))
     D = (2 + (2 if dyn == 2 else 0)) if dyn else 0
     checked = 0
     for i, (T, u) in enumerate(zip(frames, utts)):

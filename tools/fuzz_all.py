@@ -8,7 +8,7 @@ and the number of positions finite on one side only are printed, not judged -- a
 amplifies float32 noise without bound; the exact criterion is the three-part check of tests/conftest.py).
 Prints one line per case and a summary per kernel; exits non-zero on a failure.
 
-    python tools/fuzz_all.py [seed] [cases]
+    python tools/fuzz_all.py [seed] [cases] [wide | big | k1024]     (k1024: every case inside k_front1024's envelope)
 """
 import os
 import sys
@@ -24,6 +24,7 @@ orc = G.load_oracle()
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"   # wider ranges: band edges, warp, delta orders, filter / column counts, tiny shifts
+K1024 = len(sys.argv) > 3 and sys.argv[3] == "k1024"  # every case inside k_front1024's envelope (1024 points, mono, <= 80 filters, <= 16 columns or no DCT)
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"     # many long utterances per plan (whole grids, the tail split, the 4-frame pieces): a sample of them is checked
 rng = np.random.default_rng(seed)
 LOW, HIGH_CUT = 64.0, 0.0
@@ -123,16 +124,33 @@ for case in range(n_cases):
         alpha = float(rng.uniform(0.8, 1.25))
         S = int(rng.integers(4, W + 1))
         LOW, HIGH_CUT = float(rng.integers(0, 300)), float(rng.integers(0, int(sr / 8)))
+    if K1024:
+        W2, ch = 1024, 1
+        if rng.integers(0, 2):      # a short window zero padded to 1024 points (the 16-wave builds), or any window up to 1024
+            W, fft_size = int(rng.integers(64, 513)), 1024
+        else:
+            W, fft_size = int(rng.integers(513, 1025)), 0
+        S = int(rng.integers(max(8, W // 6), W + 1))
+        if rng.integers(0, 2):
+            S &= ~1                 # even shifts at even offsets: the aligned builds
+        nb = int(rng.integers(1, 81))
+        c0 = bool(rng.integers(0, 2))
+        nc = 0 if (rng.integers(0, 4) == 0 or nb < 2) else int(rng.integers(1, min(nb, 16 - (1 if c0 else 0)) + 1))
+        if nc == 0:
+            c0 = False
+        alpha = float(rng.uniform(0.8, 1.25))
     D = (l1 if dyn else 0) + (l2 if dyn == 2 else 0)
     frames = [max(int(x), 2 * D + 2) for x in rng.integers(2, 50, size=int(rng.integers(1, 6)))]
     if BIG:
         frames = [max(int(x), 2 * D + 2) for x in rng.integers(100, 1500, size=int(rng.integers(40, 300)))]
     lens = [(T - 1) * S + W + int(rng.integers(0, S)) for T in frames]
-    odd_ok = ch == 1
+    odd_ok = ch == 1 and not (K1024 and S % 2 == 0 and rng.integers(0, 4) > 0)
     offs, pos = [], int(rng.integers(0, 3)) if odd_ok else 0
     for n in lens:
         offs.append(pos)
         pos += n + (int(rng.integers(0, 5)) if odd_ok else 2 * int(rng.integers(0, 3)))
+        if K1024 and not odd_ok:
+            pos += pos & 1          # every utterance at an even offset
     pcm = (4000.0 * rng.standard_normal(pos * ch)).round().clip(-32768, 32767).astype(np.int16)
     mono = pcm if ch == 1 else ((pcm[0::2].astype(np.int32) + pcm[1::2].astype(np.int32)) >> 1).astype(np.int16)
     window = pkg.reference_window(W)

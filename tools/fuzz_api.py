@@ -2,7 +2,7 @@
 (tools/fuzz_all.py compares values with the CPU checker; this one compares the library with itself and with the checker where
 the claim is "the same bits" or "the same rows"):
 
-  1. engine bits that promise THE SAME BITS: MFX_ENGINE_NORM_TWO_KERNELS, MFX_ENGINE_DMA_SMALL_BLOCKS, MFX_ENGINE_FUSE_DELTA
+  1. engine bits that promise THE SAME BITS: MFX_ENGINE_NORM_TWO_KERNELS, MFX_ENGINE_DMA_SMALL_BLOCKS, MFX_ENGINE_FUSE_DELTA, MFX_ENGINE_FRONT1024_12_WAVES
      (where it applies), and MFX_ENGINE_STREAM_KERNELS on the batch entry == the streaming interface's rows;
   2. mfx_apply_alphas == rounds of mfx_set_alpha + mfx_apply (same bits), each against the checker;
   3. one handle, several files: set_input* -> flush -> set_input* ... (DESIGN.md B7) == a fresh handle per file;
@@ -148,7 +148,8 @@ for case in range(n_cases):
 
         # 1c. the fused kernels' batch entry: NORM_TWO_KERNELS and FUSE_DELTA the same bits; values against the checker
         outs = {}
-        for bit, label in ((0, "default"), (E.ENGINE_NORM_TWO_KERNELS, "NORM_TWO_KERNELS"), (E.ENGINE_FUSE_DELTA, "FUSE_DELTA")):
+        for bit, label in ((0, "default"), (E.ENGINE_NORM_TWO_KERNELS, "NORM_TWO_KERNELS"), (E.ENGINE_FUSE_DELTA, "FUSE_DELTA"),
+                           (E.ENGINE_FRONT1024_12_WAVES, "FRONT1024_12_WAVES")):
             mb = mk(big, engine=bit, bug_compat=False)
             mb.set_window(window)
             mb.batch_plan(offs, [len(f) for f in files])
@@ -162,7 +163,7 @@ for case in range(n_cases):
                 if not np.array_equal(mb.batch_run_host(pcm), outs[label], equal_nan=True):
                     notes.append("the first plan again: different rows")
             mb.close()
-        for label in ("NORM_TWO_KERNELS", "FUSE_DELTA"):
+        for label in ("NORM_TWO_KERNELS", "FUSE_DELTA", "FRONT1024_12_WAVES"):
             if not np.array_equal(outs[label], outs["default"], equal_nan=True):
                 notes.append("batch, engine %s: bits differ" % label)
         if norm == 0:
