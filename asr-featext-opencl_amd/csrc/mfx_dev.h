@@ -29,6 +29,20 @@ __device__ __forceinline__ float stereo_mean(uint32_t d)
     return (float)(s >> 1);
 }
 
+// Blocks are dealt to the 8 XCDs round robin (blocks b and b + 8 share one, whichever it is: MI355X_MICROARCH.md, Workgroup
+// dispatch), each XCD with its own L2.  The logical id of this block, chosen so that CONSECUTIVE ids share an XCD (bijective for
+// any grid size): consecutive chunks -- neighbouring 16-frame pieces of one utterance, W - S samples in common -- are then
+// fetched through one L2 instead of two.  A speed choice only: nothing depends on where a block really runs.
+__device__ __forceinline__ int xcd_block_id()
+{
+#ifdef MFX_NO_XCD_REMAP
+    return blockIdx.x;
+#else
+    const int n = gridDim.x, b = blockIdx.x, x = b & 7, q = n >> 3, r = n & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+#endif
+}
+
 __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

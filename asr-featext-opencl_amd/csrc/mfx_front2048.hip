@@ -228,11 +228,12 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
         x.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(((uintptr_t)bp_hi << 32) | bp_lo), 0, nbytes, 0x00020000);
         return x;
     };
+    const int block_id = xcd_block_id(); // (consecutive ids, i.e. consecutive chunks, on one XCD's L2)
     auto draw = [&]() -> int {
         int k = 0;
         if (lane == 0) k = __hip_atomic_fetch_add(s_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         k = __builtin_amdgcn_readfirstlane(k);
-        const long long cc = (long long)blockIdx.x + (long long)k * gridDim.x;
+        const long long cc = (long long)block_id + (long long)k * gridDim.x;
         return cc < p.n_chunks ? (int)cc : p.n_chunks;
     };
     // raw words of (frame f, this lane): sample pair n = l + 32 j at byte (f S + 2 n) * (STEREO ? 4 : 2)

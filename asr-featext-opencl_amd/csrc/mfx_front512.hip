@@ -340,6 +340,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
     // Block b owns chunks b, b + B, b + 2B, ...; its waves draw from that list through a counter in
     // LDS (a ds_add_rtn costs ~100 cycles and contends with the block's other waves only), so waves that the
     // SIMD arbiter favours simply take more chunks instead of finishing early and idling the CU.
+    const int block_id = xcd_block_id(); // (consecutive ids, i.e. consecutive chunks, on one XCD's L2)
     auto next_index = [&]() -> int {
         int k = 0;
         if (lane == 0) k = __hip_atomic_fetch_add(s_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
     };
     auto chunk_of = [&](int k) -> int {
         if (FUSE) return k < chunk_cnt ? chunk_base + k : p.n_chunks; // the block's own contiguous list, in order
-        const long long c = (long long)blockIdx.x + (long long)k * gridDim.x;
+        const long long c = (long long)block_id + (long long)k * gridDim.x;
         return c < p.n_chunks ? (int)c : p.n_chunks;
     };
     int v_a = next_index(), v_b = next_index(), v_nn = next_index();
@@ -809,13 +810,14 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) k_front1024(FrontParams
         const int s = x.odd0 + f * p.shift + 2 * l;
         return ALIGNED ? s * 2 : (s & ~1) * 2;
     };
+    const int block_id = xcd_block_id(); // (consecutive ids, i.e. consecutive chunks, on one XCD's L2)
     auto next_index = [&]() -> int {
         int k = 0;
         if (lane == 0) k = __hip_atomic_fetch_add(s_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return k;
     };
     auto chunk_of = [&](int k) -> int {
-        const long long c = (long long)blockIdx.x + (long long)k * gridDim.x;
+        const long long c = (long long)block_id + (long long)k * gridDim.x;
         return c < p.n_chunks ? (int)c : p.n_chunks;
     };
     int v_a = next_index(), v_b = next_index(), v_nn = next_index();

@@ -406,7 +406,8 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
     // keep the fixed round-robin deal: they are at their register budget, and the draw's bookkeeping spilled 9 more
     // registers there (C5 0.723 -> 0.759 ms).
     constexpr bool DRAW = LOG2M != 10;
-    int fixed_c = blockIdx.x * n_waves + wave; // (!DRAW: wave w of the grid takes chunks w, w + W, w + 2 W, ...)
+    const int block_id = xcd_block_id(); // (consecutive ids, i.e. consecutive chunks, on one XCD's L2)
+    int fixed_c = block_id * n_waves + wave; // (!DRAW: wave w of the grid takes chunks w, w + W, w + 2 W, ...)
     auto draw = [&]() -> int {
         if (!DRAW) {
             const int cc = fixed_c < p.n_chunks ? fixed_c : p.n_chunks;
@@ -416,7 +417,7 @@ __global__ void __launch_bounds__(LOG2M >= 11 ? 256 : (LOG2M == 10 && FUSED) ? M
         int k = 0;
         if ((tid & 63) == 0) k = __hip_atomic_fetch_add(s_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         k = __builtin_amdgcn_readfirstlane(k);
-        const long long cc = (long long)blockIdx.x + (long long)k * gridDim.x;
+        const long long cc = (long long)block_id + (long long)k * gridDim.x;
         return cc < p.n_chunks ? (int)cc : p.n_chunks;
     };
     bool fetched = false; // raw holds the frame about to be worked on
