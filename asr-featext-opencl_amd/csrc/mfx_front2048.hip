@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mfx_dev.h"
+#include "mfx_launch.h"
 
 namespace mfx {
 
@@ -591,7 +592,7 @@ hipError_t launch_front2048(const FrontParams &p, int num_cus, hipStream_t strea
     if (blocks < 1) blocks = 1;
     hipError_t err = hipSuccess;
     auto go = [&](auto kern) {
-        if (lds > 64 * 1024) err = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        err = allow_dynamic_lds((const void *)kern, lds);
         if (err == hipSuccess) hipLaunchKernelGGL(kern, dim3(blocks), dim3(nw * 64), lds, stream, p);
     };
     if (rows == kRows2048F) {

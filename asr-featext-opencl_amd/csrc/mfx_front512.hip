@@ -1157,11 +1157,7 @@ template <bool A, int NM>
 hipError_t launch512_delta(const FrontParams &p, hipStream_t stream)
 {
     const size_t lds = front512_delta_lds_bytes(p);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_front512<A, false, NM, true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    if (hipError_t e = allow_dynamic_lds((const void *)k_front512<A, false, NM, true>, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL((k_front512<A, false, NM, true>), dim3(p.n_blocks), dim3(kThreads), lds, stream, p);
     return hipGetLastError();
 }
@@ -1177,11 +1173,7 @@ hipError_t launch512(const FrontParams &p_in, hipStream_t stream)
         p.dct_mode = 0;
     }
     const size_t lds = front512_lds_bytes(p);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_front512<A, S, NM, false, STUFF, CH2>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    if (hipError_t e = allow_dynamic_lds((const void *)k_front512<A, S, NM, false, STUFF, CH2>, lds); e != hipSuccess) return e;
     // one block per CU; with fewer work items than that, one item per block (spread over the CUs: a small streaming
     // block is latency, not throughput)
     const int cap = num_cus() * (32 / kWaves) / 2; // 16 waves per CU
@@ -1215,10 +1207,7 @@ template <bool A, int NM, int WAVES>
 hipError_t launch1024(const FrontParams &p, hipStream_t stream)
 {
     const size_t lds = front1024_lds_bytes(p, WAVES);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_front1024<A, NM, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    if (hipError_t e = allow_dynamic_lds((const void *)k_front1024<A, NM, WAVES>, lds); e != hipSuccess) return e;
     int blocks = (p.n_chunks + WAVES - 1) / WAVES;
     if (blocks > num_cus()) blocks = num_cus(); // one block per CU
     if (blocks < 1) blocks = 1;

@@ -691,11 +691,7 @@ int front_reg_waves(const FrontParams &p, bool fused)
 template <int LOG2M, bool FUSED, bool PAIR, bool HALF>
 hipError_t launch_reg_inst(const FrontParams &p, int nw, size_t lds, int blocks, hipStream_t stream)
 {
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_front_reg<LOG2M, FUSED, PAIR, HALF>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    if (hipError_t e = allow_dynamic_lds((const void *)k_front_reg<LOG2M, FUSED, PAIR, HALF>, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL((k_front_reg<LOG2M, FUSED, PAIR, HALF>), dim3(blocks), dim3(64 * nw), lds, stream, p);
     return hipGetLastError();
 }
@@ -746,10 +742,7 @@ hipError_t launch_front_generic(const FrontParams &p, bool fused, hipStream_t st
     }
     const size_t lds = front_wave_lds_bytes(p, fused);
     const void *fn = fused ? (const void *)k_front_wave<true, 64> : (const void *)k_front_wave<false, 64>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    if (hipError_t e = allow_dynamic_lds(fn, lds); e != hipSuccess) return e;
     int blocks = (p.n_chunks + 3) / 4;
     // persistent blocks, as many as are RESIDENT at once (registers: 6 per CU for the fused build; the LDS may allow fewer): a
     // grid of 8 per CU where 5 fit ran in two rounds -- 8 kHz / 256 points 2.46 ms per 2 M frames against 1.78 with 8 resident

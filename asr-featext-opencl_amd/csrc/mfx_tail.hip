@@ -557,6 +557,36 @@ int num_cus()
     return cached[dev];
 }
 
+hipError_t allow_dynamic_lds(const void *func, size_t lds_bytes)
+{
+    if (lds_bytes <= 64 * 1024) return hipSuccess;
+    struct Key {
+        int dev;
+        const void *func;
+        size_t granted;
+    };
+    static thread_local Key cache[32];
+    static thread_local int used = 0, next = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    Key *slot = nullptr;
+    for (int i = 0; i < used; ++i)
+        if (cache[i].dev == dev && cache[i].func == func) {
+            if (cache[i].granted >= lds_bytes) return hipSuccess;
+            slot = &cache[i];
+            break;
+        }
+    const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    if (!slot) {
+        slot = &cache[next];
+        next = (next + 1) % 32;
+        if (used < 32) ++used;
+    }
+    *slot = Key{dev, func, lds_bytes};
+    return hipSuccess;
+}
+
 int blocks_per_cu(const void *func, int threads, size_t lds_bytes, int fallback)
 {
     struct Key {
@@ -597,10 +627,7 @@ hipError_t launch_melcep(const MelcepParams &p, hipStream_t stream)
     while (nw > 1 && melcep_lds_bytes(p, nw) > 160 * 1024) nw >>= 1;
     const size_t lds = melcep_lds_bytes(p, nw);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_melcep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    if (hipError_t e = allow_dynamic_lds((const void *)k_melcep, lds); e != hipSuccess) return e;
     int64_t blocks = ((p.n_rows + 3) / 4 + nw - 1) / nw;
     // persistent blocks: as many as are resident at once (registers allow 6 blocks of 4 waves; see launch_front_generic)
     int per_cu = blocks_per_cu((const void *)k_melcep, 64 * nw, lds, (int)std::min<size_t>(4, (160 * 1024) / lds)); // (per device and launch shape)
@@ -663,11 +690,8 @@ hipError_t launch_delta(const DeltaParams &p, hipStream_t stream)
     const int rows_t = fast16 ? kDeltaRows : RW;
     const int tiles_x = p.tiles_per_seg_max * (kDeltaRows / rows_t);
     const size_t lds = (size_t)((rows_t + 2 * D) + (rows_t + 2 * p.l2) + rows_t) * cw * sizeof(float);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fast16 ? (const void *)k_delta<true, kDeltaRows> : (const void *)k_delta<false, RW>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    if (hipError_t e = allow_dynamic_lds(fast16 ? (const void *)k_delta<true, kDeltaRows> : (const void *)k_delta<false, RW>, lds); e != hipSuccess)
+        return e;
     // grid.y is limited to 65535: split the segment list
     for (int s0 = 0; s0 < p.n_segs; s0 += 65535) {
         DeltaParams q = p;
