@@ -39,11 +39,11 @@ RCCL_PROBE_TIMEOUT_S = 60   # --collective rccl: a slow bring-up must not eat th
 # section 7).  roofline.bound stays the contract's nominal bound for this path ("hbm"); a kernel without a collected
 # profile gets no diagnosis (the label was hardcoded for every workload).
 BOUND_DIAGNOSED = {
-    "k_front512": ("valu_issue", "profiles/r03/v4_C2_pmc_summary.json: 182 VALU wave-instr per frame, ~0.8 of the issue slots"),
-    "k_front1024": ("valu_issue+lds_latency", "profiles/r03/v4_C3_pmc_summary.json: ~0.67 of the issue slots at 3 waves/SIMD, "
-                    "18 % of LDS cycles bank conflicts"),
-    "k_front2048": ("valu_issue+lds_latency", "profiles/r03/v4_C5_pmc_summary.json: ~0.65 of the issue slots at 3 waves/SIMD "
-                    "(LDS-capped occupancy)"),
+    "k_front512": ("valu_issue", "profiles/r04/v3_C2_pmc_summary.json: 182 VALU wave-instr per frame, ~0.8 of the issue slots at 4 waves/SIMD"),
+    "k_front1024": ("valu_issue+lds_latency", "profiles/r04/v3_C3_pmc_summary.json: ~0.68 of the issue slots at 4 waves/SIMD, LDS array "
+                    "0.55 busy (eight LDS phases per frame)"),
+    "k_front2048": ("valu_issue+lds_latency", "profiles/r04/v3_C5_pmc_summary.json: ~0.69 of the issue slots at 3 waves/SIMD "
+                    "(register- and LDS-capped occupancy)"),
 }
 
 WORKLOADS = {
