@@ -408,6 +408,7 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
             else
                 issue(ccur, f + 2);
             MFX_STAMP2(11);
+            const int st_first = s_mst[l]; // first bin of this lane's filter in round 0 of the mel walk (requested before the sync)
             wave_sync();
 
             MFX_STAMP2(5);
@@ -420,9 +421,12 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
 #if defined(MFX_ABLATE2048) && (MFX_ABLATE2048 == 1 || MFX_ABLATE2048 == 3)
                 for (int r = 0; r < 0; ++r) { // dev-only ablation: no mel walk
 #else
+                int st = st_first;
                 for (int r = 0; r < rounds; ++r) {
 #endif
-                    const int st = s_mst[r * 32 + l], fid = s_mfid[r * 32 + l];
+                    // (the next round's first bin is in flight during this round's trips: a round starts with ONE dependent LDS
+                    // round trip -- its first magnitudes -- instead of two; the filter id is only needed at the round's end)
+                    const int st_next = s_mst[(r + 1 < rounds ? r + 1 : r) * 32 + l], fid = s_mfid[r * 32 + l];
                     const int L = p.mel32_L[r];
                     const float *mg = plane + st;
                     float acc = 0.f;
@@ -459,6 +463,7 @@ __global__ void __launch_bounds__(kW2048 * 64, (kW2048 + 3) / 4) k_front2048(Fro
                     }
                     wrow += L;
                     lmf[fid >= 0 ? fid : lmFS - 1] = MFX_LOG(fmaxf(acc, 1e-30f)); // idle lane: the spare word
+                    st = st_next;
                 }
             }
             wave_sync();
