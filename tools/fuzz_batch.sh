@@ -1,6 +1,6 @@
 mkdir -p gpurun_out/fz
 fail=0
-for seed in 31 32 33 34; do
+for seed in ${FUZZ_SEEDS:-31 32 33 34}; do
   timeout -k 10 300 python tools/fuzz_all.py $seed 300 > gpurun_out/fz/all_$seed.txt 2>&1 || { echo "fuzz_all $seed FAIL"; fail=1; }
   tail -1 gpurun_out/fz/all_$seed.txt | cut -c1-250
   timeout -k 10 300 python tools/fuzz_all.py $seed 300 wide > gpurun_out/fz/wide_$seed.txt 2>&1 || { echo "fuzz_all wide $seed FAIL"; fail=1; }
