@@ -714,10 +714,12 @@ __global__ void __launch_bounds__(kThreads, 4) k_front512(FrontParams p) // (4 w
 //              T = (-i W_1024^(2k+1)) D:   X[2k+1] = (S + T) / 2,   X[2(255-k)+1] = conj(S - T) / 2          (phase O)
 // -- the same split arithmetic with another twiddle and the partner in lane 15 - l, register 15 - p (a plain row mirror,
 // no self-paired bins).  Phase O multiplies the samples by the window taps times W_512^m (a 2 x 2 real table per sample
-// pair) and runs first; its 16 magnitudes per lane wait in registers while phase E re-converts the same raw words.
-// Magnitudes land de-interleaved in the frame's slot (E[i] = bin 2i, O[i] = bin 2i+1); the mel walk reads two bins of
-// each per 8-byte read and adds them in ascending bin order (mfcccpu.cpp:192-220); log, DCT on the matrix pipe as in
-// k_front512 (20 K steps: at most 80 filters).
+// pair).  NO magnitude waits in registers (round 4: that is what lets the aligned builds run 4 waves per SIMD): phase E runs
+// first and stores its magnitudes straight into the slot; phase O re-converts the same raw words, transposes BESIDE the E
+// magnitudes one component at a time, and stores its own.  Magnitudes lie de-interleaved in the frame's slot (E[i] = bin 2i,
+// O[i] = bin 2i+1); the mel walk reads two bins of each per 8-byte read and adds them in ascending bin order
+// (mfcccpu.cpp:192-220), keeps its log energies in registers and lays them over the E magnitudes when every lane has finished
+// reading; DCT on the matrix pipe as in k_front512 (20 K steps: at most 80 filters).
 // ------------------------------------------------------------------------------------------------
 constexpr int kSlotL = 544;       // dwords per frame slot: E magnitudes [0, 264) | O magnitudes [264, 528).  Phase E transposes through
                                   // [0, 512) before any magnitude lands; phase O, with the E magnitudes in place, through
